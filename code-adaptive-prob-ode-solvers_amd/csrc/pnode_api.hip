@@ -1,0 +1,589 @@
+// C-ABI layer (include/pnode.h): handle management, host-side slot bookkeeping, launches.
+// No torch types, no Python: plain pointers and sizes. One handle = one GPU + one HIP stream.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/pnode.h"
+#include "pnode_device.hpp"
+
+using namespace pnode;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      return fail(PNODE_EDEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));         \
+  } while (0)
+
+template <class T>
+int dalloc(T** p, size_t count) {
+  *p = nullptr;
+  if (count == 0) return PNODE_OK;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)));
+  HIP_TRY(hipMemset(*p, 0, count * sizeof(T)));
+  return PNODE_OK;
+}
+
+void fill_iwp(int nu, IwpConst* K) {
+  const int n = nu + 1;
+  std::memset(K, 0, sizeof(*K));
+  auto binom = [](int a, int b) {
+    double r = 1.0;
+    for (int i = 1; i <= b; ++i) r = r * double(a - b + i) / double(i);
+    return r;
+  };
+  double q[kMaxN][kMaxN], l[kMaxN][kMaxN];
+  for (int i = 0; i < n; ++i) {
+    double f = 1.0;
+    for (int m = 2; m <= nu - i; ++m) f *= double(m);
+    K->fact[i] = f;
+    for (int j = 0; j < n; ++j) {
+      K->a[i][j] = (j >= i) ? std::round(binom(nu - i, nu - j)) : 0.0;
+      q[i][j] = 1.0 / double(2 * nu + 1 - i - j);
+      l[i][j] = 0.0;
+    }
+  }
+  // lower Cholesky of the (flipped) Hilbert matrix
+  for (int j = 0; j < n; ++j) {
+    double s = q[j][j];
+    for (int k = 0; k < j; ++k) s -= l[j][k] * l[j][k];
+    l[j][j] = std::sqrt(s);
+    for (int i = j + 1; i < n; ++i) {
+      double t = q[i][j];
+      for (int k = 0; k < j; ++k) t -= l[i][k] * l[j][k];
+      l[i][j] = t / l[j][j];
+    }
+  }
+  for (int i = 0; i < n; ++i) {
+    K->qdiag_sqrt[i] = std::sqrt(q[i][i]);
+    for (int j = 0; j < n; ++j) K->qsT[j][i] = l[i][j];
+  }
+}
+
+__global__ void gather_u_kernel(const double* __restrict__ mean, const StepArg* __restrict__ args, double* __restrict__ out,
+                                int B, int n, int d, int G, int g) {
+  const int b = blockIdx.x;
+  const double* m = mean + (size_t(args[b].dst) * B + b) * n * d;
+  for (int j = threadIdx.x; j < d; j += blockDim.x) out[(size_t(b) * G + g) * d + j] = m[j];
+}
+
+}  // namespace
+
+struct pnode_batch {
+  pnode_config cfg{};
+  int n = 0, D = 0;
+  bool dense = false;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  IsoView iso{};
+  DenseView dn{};
+  IwpConst* dK = nullptr;
+  StepArg* dArgs = nullptr;
+  InterpArg* dIargs = nullptr;
+  int32_t* dFilled = nullptr;
+  double *dAtol = nullptr, *dRtol = nullptr, *dPrm = nullptr, *dErr = nullptr;
+  StepArg* hArgs = nullptr;     // pinned
+  InterpArg* hIargs = nullptr;  // pinned
+  double* hErr = nullptr;       // pinned
+  // host bookkeeping, per trajectory
+  std::vector<double> t_sf, t_if, dt_pending;
+  std::vector<int8_t> s_sf, s_if, s_pr;
+  std::vector<int64_t> steps;
+  std::vector<uint8_t> pending;
+  bool initialised = false;
+  std::vector<void*> allocations;
+};
+
+extern "C" {
+
+const char* pnode_last_error(void) { return g_err.c_str(); }
+int pnode_version(void) { return 100; }
+
+int pnode_device_count(void) {
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) return fail(PNODE_EDEVICE, hipGetErrorString(e));
+  return c;
+}
+
+int pnode_destroy(pnode_batch* h) {
+  if (!h) return PNODE_OK;
+  (void)hipSetDevice(h->cfg.device);
+  for (void* p : h->allocations) (void)hipFree(p);
+  if (h->hArgs) (void)hipHostFree(h->hArgs);
+  if (h->hIargs) (void)hipHostFree(h->hIargs);
+  if (h->hErr) (void)hipHostFree(h->hErr);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return PNODE_OK;
+}
+
+#define ALLOC(ptr, count)                                 \
+  do {                                                    \
+    int rc_ = dalloc(&(ptr), (count));                    \
+    if (rc_ != PNODE_OK) {                                \
+      pnode_destroy(h);                                   \
+      return rc_;                                         \
+    }                                                     \
+    if (ptr) h->allocations.push_back((void*)(ptr));      \
+  } while (0)
+
+int pnode_create(const pnode_config* cfg, pnode_batch** out) {
+  if (!cfg || !out) return fail(PNODE_EINVAL, "null argument");
+  *out = nullptr;
+  if (cfg->batch <= 0 || cfg->d <= 0) return fail(PNODE_EINVAL, "batch and d must be positive");
+  if (cfg->nu < 1 || cfg->nu > 8) return fail(PNODE_EINVAL, "nu must be in 1..8");
+  if (cfg->ode_order < 1 || cfg->ode_order > 2 || cfg->ode_order > cfg->nu)
+    return fail(PNODE_EINVAL, "ode_order must be 1 or 2 and <= nu");
+  if (cfg->model != PNODE_MODEL_ISOTROPIC && cfg->model != PNODE_MODEL_DENSE) return fail(PNODE_EINVAL, "bad model");
+  if (cfg->correction != PNODE_CORR_TS0 && cfg->correction != PNODE_CORR_TS1) return fail(PNODE_EINVAL, "bad correction");
+  if (cfg->model == PNODE_MODEL_ISOTROPIC && cfg->correction == PNODE_CORR_TS1)
+    return fail(PNODE_EINVAL, "correction_ts1 needs the dense model");
+  if (cfg->strategy != PNODE_STRATEGY_FILTER && cfg->strategy != PNODE_STRATEGY_FIXEDPOINT)
+    return fail(PNODE_EINVAL, "bad strategy");
+  if (cfg->model == PNODE_MODEL_DENSE && cfg->strategy != PNODE_STRATEGY_FILTER)
+    return fail(PNODE_EINVAL, "dense model: only strategy_filter is implemented");
+  if (cfg->calibration != PNODE_CALIB_NONE && cfg->calibration != PNODE_CALIB_DYNAMIC)
+    return fail(PNODE_EINVAL, "bad calibration");
+  if (cfg->num_vf_params < 0 || cfg->num_vf_params > PNODE_MAX_VF_PARAMS) return fail(PNODE_EINVAL, "bad num_vf_params");
+  if (cfg->num_checkpoints < 0) return fail(PNODE_EINVAL, "bad num_checkpoints");
+  // vector-field shape checks
+  const int d = cfg->d, k = cfg->ode_order;
+  auto need = [&](bool ok, const char* what) { return ok ? PNODE_OK : fail(PNODE_EINVAL, what); };
+  int rc = PNODE_OK;
+  switch (cfg->vf_id) {
+    case PNODE_VF_BRUSSELATOR: rc = need(d % 2 == 0 && k == 1 && cfg->num_vf_params <= 1, "brusselator: d even, order 1"); break;
+    case PNODE_VF_VDP_ORDER2: rc = need(d == 1 && k == 2 && cfg->num_vf_params == 1, "vdp (order 2): d=1, params [mu]"); break;
+    case PNODE_VF_VDP_ORDER1: rc = need(d == 2 && k == 1 && cfg->num_vf_params == 1, "vdp (order 1): d=2, params [mu]"); break;
+    case PNODE_VF_RIGID_BODY: rc = need(d == 3 && k == 1 && cfg->num_vf_params == 3, "rigid body: d=3, params [a,b,c]"); break;
+    case PNODE_VF_PLEIADES_ORDER2: rc = need(d == 14 && k == 2, "pleiades (order 2): d=14"); break;
+    case PNODE_VF_PLEIADES_ORDER1: rc = need(d == 28 && k == 1, "pleiades (order 1): d=28"); break;
+    case PNODE_VF_LOGISTIC: rc = need(k == 1 && cfg->num_vf_params == 2, "logistic: order 1, params [a,b]"); break;
+    case PNODE_VF_LINEAR: rc = need(k == 1 && cfg->num_vf_params == 1, "linear: order 1, params [lam]"); break;
+    default: rc = fail(PNODE_EINVAL, "unknown vf_id");
+  }
+  if (rc != PNODE_OK) return rc;
+  if (cfg->num_vf_params > 0 && !cfg->vf_params) return fail(PNODE_EINVAL, "vf_params is null");
+
+  HIP_TRY(hipSetDevice(cfg->device));
+  pnode_batch* h = new (std::nothrow) pnode_batch();
+  if (!h) return fail(PNODE_EDEVICE, "host allocation failed");
+  h->cfg = *cfg;
+  h->cfg.vf_params = nullptr;
+  h->n = cfg->nu + 1;
+  h->D = h->n * d;
+  h->dense = cfg->model == PNODE_MODEL_DENSE;
+  const size_t B = cfg->batch, n = h->n, D = h->D, Kc = cfg->num_checkpoints;
+  HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreate(&h->ev0));
+  HIP_TRY(hipEventCreate(&h->ev1));
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->hArgs), B * sizeof(StepArg)));
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->hIargs), B * sizeof(InterpArg)));
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->hErr), B * sizeof(double)));
+
+  ALLOC(h->dK, 1);
+  ALLOC(h->dArgs, B);
+  ALLOC(h->dIargs, B);
+  ALLOC(h->dFilled, B);
+  ALLOC(h->dAtol, B);
+  ALLOC(h->dRtol, B);
+  ALLOC(h->dErr, B);
+  const size_t nprm = size_t(cfg->num_vf_params) * (cfg->vf_params_per_trajectory ? B : 1);
+  ALLOC(h->dPrm, nprm);
+  if (nprm) HIP_TRY(hipMemcpy(h->dPrm, cfg->vf_params, nprm * sizeof(double), hipMemcpyHostToDevice));
+  IwpConst hk;
+  fill_iwp(cfg->nu, &hk);
+  HIP_TRY(hipMemcpy(h->dK, &hk, sizeof(hk), hipMemcpyHostToDevice));
+
+  if (!h->dense) {
+    IsoView& v = h->iso;
+    v.B = int(B); v.d = d; v.k = k; v.n = int(n); v.K = int(Kc);
+    v.fixedpoint = cfg->strategy == PNODE_STRATEGY_FIXEDPOINT;
+    v.dynamic = cfg->calibration == PNODE_CALIB_DYNAMIC;
+    v.vf_id = cfg->vf_id; v.P = cfg->num_vf_params; v.prm_per_traj = cfg->vf_params_per_trajectory;
+    ALLOC(v.mean, 3 * B * n * d);
+    ALLOC(v.fac, 3 * B * n * n);
+    ALLOC(v.sigma, 3 * B);
+    ALLOC(v.ck_mean, B * Kc * n * d);
+    ALLOC(v.ck_fac, B * Kc * n * n);
+    ALLOC(v.ck_steps, B * Kc);
+    if (v.fixedpoint) {
+      ALLOC(v.cG, 3 * B * n * n);
+      ALLOC(v.cxi, 3 * B * n * d);
+      ALLOC(v.cLam, 3 * B * n * n);
+      ALLOC(v.ck_G, B * Kc * n * n);
+      ALLOC(v.ck_xi, B * Kc * n * d);
+      ALLOC(v.ck_Lam, B * Kc * n * n);
+    }
+    v.atol = h->dAtol; v.rtol = h->dRtol; v.prm = nprm ? h->dPrm : nullptr; v.errnorm = h->dErr;
+  } else {
+    DenseView& v = h->dn;
+    v.B = int(B); v.d = d; v.k = k; v.n = int(n); v.D = int(D); v.K = int(Kc);
+    v.ts1 = cfg->correction == PNODE_CORR_TS1;
+    v.dynamic = cfg->calibration == PNODE_CALIB_DYNAMIC;
+    v.vf_id = cfg->vf_id; v.P = cfg->num_vf_params; v.prm_per_traj = cfg->vf_params_per_trajectory;
+    ALLOC(v.mean, 3 * B * n * d);
+    ALLOC(v.U, 3 * B * D * D);
+    ALLOC(v.sigma, 3 * B);
+    ALLOC(v.ck_mean, B * Kc * n * d);
+    ALLOC(v.ck_steps, B * Kc);
+    ALLOC(v.M, B * D * D);
+    ALLOC(v.R, B * D * D);
+    ALLOC(v.J, B * d * size_t(k) * d);
+    ALLOC(v.z, B * d);
+    ALLOC(v.err, B * d);
+    ALLOC(v.Ft, B * d * D);
+    ALLOC(v.X, B * D * d);
+    ALLOC(v.S, B * d * d);
+    ALLOC(v.sig_new, B);
+    v.atol = h->dAtol; v.rtol = h->dRtol; v.prm = nprm ? h->dPrm : nullptr; v.errnorm = h->dErr;
+  }
+  h->t_sf.assign(B, 0.0);
+  h->t_if.assign(B, 0.0);
+  h->dt_pending.assign(B, 0.0);
+  h->s_sf.assign(B, 0);
+  h->s_if.assign(B, 0);
+  h->s_pr.assign(B, 1);
+  h->steps.assign(B, 0);
+  h->pending.assign(B, 0);
+  // default tolerances (ivpsolve.adaptive defaults: atol 1e-4, rtol 1e-2)
+  std::vector<double> a(B, 1e-4), r(B, 1e-2);
+  HIP_TRY(hipMemcpy(h->dAtol, a.data(), B * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->dRtol, r.data(), B * sizeof(double), hipMemcpyHostToDevice));
+  *out = h;
+  return PNODE_OK;
+}
+
+static double* mean_base(pnode_batch* h) { return h->dense ? h->dn.mean : h->iso.mean; }
+static double* sigma_base(pnode_batch* h) { return h->dense ? h->dn.sigma : h->iso.sigma; }
+
+int pnode_set_initial(pnode_batch* h, const double* tcoeffs, const double* t0, const double* output_scale) {
+  if (!h || !tcoeffs || !t0 || !output_scale) return fail(PNODE_EINVAL, "null argument");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  const size_t B = h->cfg.batch, n = h->n, d = h->cfg.d, D = h->D;
+  double* mean = mean_base(h);
+  double* sig = sigma_base(h);
+  HIP_TRY(hipMemcpyAsync(mean, tcoeffs, B * n * d * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(sig, output_scale, B * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (!h->dense) {
+    HIP_TRY(hipMemsetAsync(h->iso.fac, 0, 3 * B * n * n * sizeof(double), h->stream));
+    if (h->iso.fixedpoint) {
+      std::vector<double> eye(B * n * n, 0.0);
+      for (size_t b = 0; b < B; ++b)
+        for (size_t i = 0; i < n; ++i) eye[(b * n + i) * n + i] = 1.0;
+      HIP_TRY(hipMemcpyAsync(h->iso.cG, eye.data(), B * n * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+      HIP_TRY(hipMemsetAsync(h->iso.cxi, 0, 3 * B * n * d * sizeof(double), h->stream));
+      HIP_TRY(hipMemsetAsync(h->iso.cLam, 0, 3 * B * n * n * sizeof(double), h->stream));
+      HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+  } else {
+    HIP_TRY(hipMemsetAsync(h->dn.U, 0, B * D * D * sizeof(double), h->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  for (size_t b = 0; b < B; ++b) {
+    h->t_sf[b] = h->t_if[b] = t0[b];
+    h->s_sf[b] = h->s_if[b] = 0;
+    h->s_pr[b] = 1;
+    h->steps[b] = 0;
+    h->pending[b] = 0;
+  }
+  h->initialised = true;
+  return PNODE_OK;
+}
+
+int pnode_set_tolerances(pnode_batch* h, const double* atol, const double* rtol) {
+  if (!h || !atol || !rtol) return fail(PNODE_EINVAL, "null argument");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  const size_t B = h->cfg.batch;
+  for (size_t b = 0; b < B; ++b)
+    if (!(atol[b] >= 0.0) || !(rtol[b] >= 0.0) || (atol[b] == 0.0 && rtol[b] == 0.0))
+      return fail(PNODE_EINVAL, "tolerances must be non-negative and not both zero");
+  HIP_TRY(hipMemcpy(h->dAtol, atol, B * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->dRtol, rtol, B * sizeof(double), hipMemcpyHostToDevice));
+  return PNODE_OK;
+}
+
+static void enqueue_step(pnode_batch* h, const StepArg* dargs) {
+  if (h->dense)
+    dense_launch_step(h->dn, dargs, h->dK, h->stream);
+  else
+    iso_launch_step(h->iso, dargs, h->dK, h->stream);
+}
+
+int pnode_attempt_step(pnode_batch* h, const double* dt, const uint8_t* active, double* err_norm_out) {
+  if (!h || !dt || !active || !err_norm_out) return fail(PNODE_EINVAL, "null argument");
+  if (!h->initialised) return fail(PNODE_ESTATE, "set_initial has not been called");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  const size_t B = h->cfg.batch;
+  for (size_t b = 0; b < B; ++b) {
+    StepArg& a = h->hArgs[b];
+    a.dt = dt[b];
+    a.t = h->t_sf[b];
+    a.src = h->s_sf[b];
+    a.dst = h->s_pr[b];
+    a.active = active[b] ? 1 : 0;
+    a.pad = 0;
+    if (active[b] && !(dt[b] > 0.0)) return fail(PNODE_EINVAL, "dt must be positive for active trajectories");
+    h->pending[b] = active[b] ? 1 : 0;
+    h->dt_pending[b] = dt[b];
+  }
+  HIP_TRY(hipMemcpyAsync(h->dArgs, h->hArgs, B * sizeof(StepArg), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipEventRecord(h->ev0, h->stream));
+  enqueue_step(h, h->dArgs);
+  HIP_TRY(hipEventRecord(h->ev1, h->stream));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(h->hErr, h->dErr, B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  for (size_t b = 0; b < B; ++b)
+    if (active[b]) err_norm_out[b] = h->hErr[b];
+  return PNODE_OK;
+}
+
+int pnode_commit(pnode_batch* h, const uint8_t* accept) {
+  if (!h || !accept) return fail(PNODE_EINVAL, "null argument");
+  if (!h->initialised) return fail(PNODE_ESTATE, "set_initial has not been called");
+  const size_t B = h->cfg.batch;
+  for (size_t b = 0; b < B; ++b) {
+    if (!accept[b]) continue;
+    if (!h->pending[b]) return fail(PNODE_ESTATE, "commit without a pending attempt");
+    h->pending[b] = 0;
+    h->s_if[b] = h->s_sf[b];
+    h->t_if[b] = h->t_sf[b];
+    h->s_sf[b] = h->s_pr[b];
+    h->t_sf[b] += h->dt_pending[b];
+    h->steps[b] += 1;
+    int8_t fr = 0;
+    while (fr == h->s_if[b] || fr == h->s_sf[b]) ++fr;
+    h->s_pr[b] = fr;
+  }
+  return PNODE_OK;
+}
+
+static int run_interp(pnode_batch* h, const double* t, const int32_t* slot, bool at_step) {
+  if (!h || !slot || (!at_step && !t)) return fail(PNODE_EINVAL, "null argument");
+  if (!h->initialised) return fail(PNODE_ESTATE, "set_initial has not been called");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  const size_t B = h->cfg.batch;
+  for (size_t b = 0; b < B; ++b) {
+    InterpArg& a = h->hIargs[b];
+    a.ckpt = slot[b];
+    if (slot[b] >= h->cfg.num_checkpoints) return fail(PNODE_EINVAL, "checkpoint slot out of range");
+    a.t = at_step ? h->t_sf[b] : t[b];
+    a.t0 = h->t_if[b];
+    a.t1 = h->t_sf[b];
+    a.s0 = h->s_if[b];
+    a.s1 = h->s_sf[b];
+    a.at_step = at_step ? 1 : 0;
+    a.steps = h->steps[b];
+    if (slot[b] >= 0 && !at_step) {
+      if (!(t[b] > h->t_if[b]) || !(t[b] < h->t_sf[b]))
+        return fail(PNODE_EINVAL, "interpolation time outside (INTERP_FROM.t, STEP_FROM.t)");
+      if (h->s_if[b] == h->s_sf[b]) return fail(PNODE_ESTATE, "interpolate needs an accepted step first");
+    }
+  }
+  HIP_TRY(hipMemcpyAsync(h->dIargs, h->hIargs, B * sizeof(InterpArg), hipMemcpyHostToDevice, h->stream));
+  if (h->dense)
+    dense_launch_interp(h->dn, h->dIargs, h->dK, h->stream);
+  else
+    iso_launch_interp(h->iso, h->dIargs, h->dK, h->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  for (size_t b = 0; b < B; ++b) {
+    if (slot[b] < 0) continue;
+    if (at_step) {
+      h->s_if[b] = h->s_sf[b];
+      h->t_if[b] = h->t_sf[b];
+      int8_t fr = 0;
+      while (fr == h->s_sf[b]) ++fr;
+      h->s_pr[b] = fr;
+    } else if (!h->dense) {
+      h->t_if[b] = t[b];  // isotropic: INTERP_FROM was advanced to the checkpoint in place
+    }
+  }
+  return PNODE_OK;
+}
+
+int pnode_interpolate(pnode_batch* h, const double* t, const int32_t* slot) { return run_interp(h, t, slot, false); }
+int pnode_checkpoint_at_step(pnode_batch* h, const int32_t* slot) { return run_interp(h, nullptr, slot, true); }
+
+int pnode_solve_fixed_grid(pnode_batch* h, const double* grid, int32_t G, int32_t per_traj, double* u_out) {
+  if (!h || !grid || !u_out || G < 1) return fail(PNODE_EINVAL, "bad argument");
+  if (!h->initialised) return fail(PNODE_ESTATE, "set_initial has not been called");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  const size_t B = h->cfg.batch, n = h->n, d = h->cfg.d;
+  std::vector<StepArg> all(size_t(G) * B);
+  // step g (1-based) goes from grid[g-1] to grid[g]; entry 0 only carries the initial slot
+  std::vector<int8_t> sf = h->s_sf, si = h->s_if, sp = h->s_pr;
+  for (size_t b = 0; b < B; ++b) {
+    all[b] = StepArg{0.0, 0.0, sf[b], sf[b], 0, 0};
+  }
+  for (int g = 1; g < G; ++g)
+    for (size_t b = 0; b < B; ++b) {
+      const double* gr = per_traj ? grid + b * G : grid;
+      StepArg& a = all[size_t(g) * B + b];
+      a.dt = gr[g] - gr[g - 1];
+      a.t = gr[g - 1];
+      if (!(a.dt > 0.0)) return fail(PNODE_EINVAL, "grid must be strictly increasing");
+      a.src = sf[b];
+      a.dst = sp[b];
+      a.active = 1;
+      a.pad = 0;
+      si[b] = sf[b];
+      sf[b] = sp[b];
+      int8_t fr = 0;
+      while (fr == si[b] || fr == sf[b]) ++fr;
+      sp[b] = fr;
+    }
+  StepArg* dAll = nullptr;
+  double* dU = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dAll), all.size() * sizeof(StepArg)));
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&dU), B * size_t(G) * d * sizeof(double));
+  if (e != hipSuccess) {
+    (void)hipFree(dAll);
+    return fail(PNODE_EDEVICE, hipGetErrorString(e));
+  }
+  auto cleanup = [&]() {
+    (void)hipFree(dAll);
+    (void)hipFree(dU);
+  };
+  e = hipMemcpyAsync(dAll, all.data(), all.size() * sizeof(StepArg), hipMemcpyHostToDevice, h->stream);
+  if (e != hipSuccess) { cleanup(); return fail(PNODE_EDEVICE, hipGetErrorString(e)); }
+  double* mean = mean_base(h);
+  HIP_TRY(hipEventRecord(h->ev0, h->stream));
+  for (int g = 0; g < G; ++g) {
+    if (g > 0) enqueue_step(h, dAll + size_t(g) * B);
+    hipLaunchKernelGGL(gather_u_kernel, dim3(unsigned(B)), dim3(64), 0, h->stream, mean, dAll + size_t(g) * B, dU, int(B),
+                       int(n), int(d), G, g);
+  }
+  HIP_TRY(hipEventRecord(h->ev1, h->stream));
+  e = hipMemcpyAsync(u_out, dU, B * size_t(G) * d * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (e == hipSuccess) e = hipGetLastError();
+  cleanup();
+  if (e != hipSuccess) return fail(PNODE_EDEVICE, hipGetErrorString(e));
+  for (size_t b = 0; b < B; ++b) {
+    const double* gr = per_traj ? grid + b * G : grid;
+    h->s_sf[b] = sf[b];
+    h->s_if[b] = si[b];
+    h->s_pr[b] = sp[b];
+    h->t_if[b] = G > 1 ? gr[G - 2] : h->t_sf[b];
+    h->t_sf[b] = gr[G - 1];
+    h->steps[b] += G - 1;
+    h->pending[b] = 0;
+  }
+  return PNODE_OK;
+}
+
+static int8_t slot_of(pnode_batch* h, int which, size_t b) {
+  return which == 0 ? h->s_sf[b] : (which == 1 ? h->s_if[b] : h->s_pr[b]);
+}
+
+int pnode_read_mean(pnode_batch* h, int32_t which, double* out) {
+  if (!h || !out || which < 0 || which > 2) return fail(PNODE_EINVAL, "bad argument");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  const size_t B = h->cfg.batch, nd = size_t(h->n) * h->cfg.d;
+  std::vector<double> tmp(3 * B * nd);
+  HIP_TRY(hipMemcpy(tmp.data(), mean_base(h), tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+  for (size_t b = 0; b < B; ++b)
+    std::memcpy(out + b * nd, tmp.data() + (size_t(slot_of(h, which, b)) * B + b) * nd, nd * sizeof(double));
+  return PNODE_OK;
+}
+
+int pnode_read_time(pnode_batch* h, double* t_out, int64_t* steps_out) {
+  if (!h) return fail(PNODE_EINVAL, "null handle");
+  const size_t B = h->cfg.batch;
+  for (size_t b = 0; b < B; ++b) {
+    if (t_out) t_out[b] = h->t_sf[b];
+    if (steps_out) steps_out[b] = h->steps[b];
+  }
+  return PNODE_OK;
+}
+
+int pnode_read_output_scale(pnode_batch* h, int32_t which, double* out) {
+  if (!h || !out || which < 0 || which > 2) return fail(PNODE_EINVAL, "bad argument");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  const size_t B = h->cfg.batch;
+  std::vector<double> tmp(3 * B);
+  HIP_TRY(hipMemcpy(tmp.data(), sigma_base(h), tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+  for (size_t b = 0; b < B; ++b) out[b] = tmp[size_t(slot_of(h, which, b)) * B + b];
+  return PNODE_OK;
+}
+
+int pnode_read_factor(pnode_batch* h, int32_t which, double* out) {
+  if (!h || !out || which < 0 || which > 2) return fail(PNODE_EINVAL, "bad argument");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  const size_t B = h->cfg.batch;
+  const size_t m = h->dense ? size_t(h->D) : size_t(h->n);
+  const double* base = h->dense ? h->dn.U : h->iso.fac;
+  std::vector<double> tmp(m * m);
+  for (size_t b = 0; b < B; ++b) {
+    HIP_TRY(hipMemcpy(tmp.data(), base + (size_t(slot_of(h, which, b)) * B + b) * m * m, m * m * sizeof(double),
+                      hipMemcpyDeviceToHost));
+    if (h->dense) {  // stored as L (Sigma = L L^T): hand out R = L^T
+      for (size_t i = 0; i < m; ++i)
+        for (size_t j = 0; j < m; ++j) out[b * m * m + i * m + j] = tmp[j * m + i];
+    } else {
+      std::memcpy(out + b * m * m, tmp.data(), m * m * sizeof(double));
+    }
+  }
+  return PNODE_OK;
+}
+
+int pnode_read_checkpoint_means(pnode_batch* h, double* out) {
+  if (!h || !out) return fail(PNODE_EINVAL, "null argument");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  const size_t cnt = size_t(h->cfg.batch) * h->cfg.num_checkpoints * h->n * h->cfg.d;
+  if (cnt == 0) return PNODE_OK;
+  HIP_TRY(hipMemcpy(out, h->dense ? h->dn.ck_mean : h->iso.ck_mean, cnt * sizeof(double), hipMemcpyDeviceToHost));
+  return PNODE_OK;
+}
+
+int pnode_smooth_checkpoint_means(pnode_batch* h, const int32_t* num_filled, double* out) {
+  if (!h || !num_filled || !out) return fail(PNODE_EINVAL, "null argument");
+  if (h->dense || !h->iso.fixedpoint) return fail(PNODE_EINVAL, "smoothing needs the isotropic fixedpoint strategy");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  const size_t B = h->cfg.batch, K = h->cfg.num_checkpoints;
+  for (size_t b = 0; b < B; ++b)
+    if (num_filled[b] < 0 || size_t(num_filled[b]) > K) return fail(PNODE_EINVAL, "num_filled out of range");
+  const size_t cnt = B * (K + 1) * h->n * h->cfg.d;
+  double* dOut = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dOut), cnt * sizeof(double)));
+  hipError_t e = hipMemsetAsync(dOut, 0, cnt * sizeof(double), h->stream);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(h->dFilled, num_filled, B * sizeof(int32_t), hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess) {
+    iso_launch_smooth(h->iso, h->dFilled, dOut, h->stream);
+    e = hipMemcpyAsync(out, dOut, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  (void)hipFree(dOut);
+  if (e != hipSuccess) return fail(PNODE_EDEVICE, hipGetErrorString(e));
+  return PNODE_OK;
+}
+
+int pnode_last_step_ms(pnode_batch* h, float* ms_out) {
+  if (!h || !ms_out) return fail(PNODE_EINVAL, "null argument");
+  HIP_TRY(hipEventElapsedTime(ms_out, h->ev0, h->ev1));
+  return PNODE_OK;
+}
+
+void* pnode_stream(pnode_batch* h) { return h ? (void*)h->stream : nullptr; }
+
+}  // extern "C"

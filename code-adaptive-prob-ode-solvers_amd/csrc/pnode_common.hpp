@@ -1,0 +1,88 @@
+// Shared device-side definitions for the pnode kernels (gfx950 / CDNA4, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pnode_vf.hpp"
+
+namespace pnode {
+
+constexpr int kWave = 64;
+constexpr int kMaxN = 9;  // nu <= 8
+
+// Per-trajectory arguments of one batched attempt (uploaded by the host every step).
+struct StepArg {
+  double dt;
+  double t;        // time of the source state
+  int32_t src;     // state slot read (STEP_FROM)
+  int32_t dst;     // state slot written (PROPOSED)
+  int32_t active;  // 0: trajectory skipped
+  int32_t pad;
+};
+
+// Per-trajectory arguments of one batched checkpoint interpolation.
+struct InterpArg {
+  double t;        // checkpoint time
+  double t0;       // INTERP_FROM time
+  double t1;       // STEP_FROM time
+  int32_t s0;      // INTERP_FROM slot (updated in place)
+  int32_t s1;      // STEP_FROM slot (backward model updated in place for fixedpoint)
+  int32_t ckpt;    // checkpoint slot, < 0: skip
+  int32_t at_step; // 1: STEP_FROM.t == checkpoint (no interpolation)
+  int64_t steps;   // num_steps recorded with the checkpoint
+};
+
+// IWP(nu) constants in preconditioned coordinates, computed on the host in fp64.
+//   a[i][k]   = binom(nu-i, nu-k)           (upper triangular)
+//   qsT[c][i] = chol(Qbar)^T                (upper triangular),  Qbar[i][j] = 1/(2nu+1-i-j)
+//   fact[i]   = (nu-i)!
+struct IwpConst {
+  double a[kMaxN][kMaxN];
+  double qsT[kMaxN][kMaxN];
+  double fact[kMaxN];
+  double qdiag_sqrt[kMaxN];  // sqrt(Qbar[i][i]) = || row i of chol(Qbar) ||
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+  return v;
+}
+
+// p_i = dt^(nu-i+1/2) / (nu-i)!,  pinv_i = 1/p_i   (probdiffeq preconditioner_diagonal)
+template <int N>
+__device__ __forceinline__ void preconditioner(double dt, const IwpConst& K, double (&p)[N], double (&pinv)[N]) {
+  const double adt = fabs(dt);
+  const double sq = sqrt(adt);
+  double pw = sq;  // dt^(0.5 + m), m = nu - i
+#pragma unroll
+  for (int i = N - 1; i >= 0; --i) {
+    p[i] = pw / K.fact[i];
+    pinv[i] = K.fact[i] / pw;
+    pw *= adt;
+  }
+}
+
+// Rotate the row x (length N) into the upper-triangular R (N x N) with Givens rotations:
+// afterwards R^T R (new) = R^T R (old) + x^T x. Orthogonal transformations only.
+template <int N>
+__device__ __forceinline__ void givens_rotate_in(double (&R)[N][N], double (&x)[N]) {
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const double xj = x[j];
+    if (xj != 0.0) {
+      const double rjj = R[j][j];
+      const double r = sqrt(rjj * rjj + xj * xj);
+      const double c = rjj / r, s = xj / r;
+      R[j][j] = r;
+#pragma unroll
+      for (int l = j + 1; l < N; ++l) {
+        const double rl = R[j][l], xl = x[l];
+        R[j][l] = c * rl + s * xl;
+        x[l] = c * xl - s * rl;
+      }
+    }
+  }
+}
+
+}  // namespace pnode

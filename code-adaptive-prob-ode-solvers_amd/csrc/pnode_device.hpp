@@ -1,0 +1,61 @@
+// Device views + launcher prototypes shared by the kernel translation units and the C-ABI layer.
+#pragma once
+#include "pnode_common.hpp"
+
+namespace pnode {
+
+// Isotropic model: device pointers for one batch (see pnode_api.hip for the allocation).
+struct IsoView {
+  int B, d, k, n, K;  // batch, ODE dim, ode order, nu+1, checkpoint capacity
+  int fixedpoint, dynamic, vf_id, P, prm_per_traj;
+  double* mean;   // [3][B][n][d]
+  double* fac;    // [3][B][n][n]   Sigma = fac^T fac
+  double* cG;     // [3][B][n][n]   running backward transition (fixedpoint)
+  double* cxi;    // [3][B][n][d]
+  double* cLam;   // [3][B][n][n]   upper triangular, Lambda = cLam^T cLam
+  double* sigma;  // [3][B]
+  const double* atol;  // [B]
+  const double* rtol;  // [B]
+  const double* prm;   // [P] or [B][P]
+  double* errnorm;     // [B]
+  double* ck_mean;     // [B][K][n][d]
+  double* ck_fac;      // [B][K][n][n]
+  double* ck_G;        // [B][K][n][n]
+  double* ck_xi;       // [B][K][n][d]
+  double* ck_Lam;      // [B][K][n][n]
+  int64_t* ck_steps;   // [B][K]
+};
+
+void iso_launch_step(const IsoView& v, const StepArg* args, const IwpConst* K, hipStream_t s);
+void iso_launch_interp(const IsoView& v, const InterpArg* args, const IwpConst* K, hipStream_t s);
+void iso_launch_smooth(const IsoView& v, const int32_t* num_filled, double* out, hipStream_t s);
+
+// Dense model (EKF1 / EKF0 with a full D x D factor), D = n*d.
+struct DenseView {
+  int B, d, k, n, D, K;
+  int ts1, dynamic, vf_id, P, prm_per_traj;
+  double* mean;   // [3][B][n][d]
+  double* U;      // [3][B][D][D]   Sigma = U^T U (row-major)
+  double* sigma;  // [3][B]
+  const double* atol;
+  const double* rtol;
+  const double* prm;
+  double* errnorm;  // [B]
+  double* ck_mean;  // [B][K][n][d]
+  int64_t* ck_steps;
+  // per-attempt scratch
+  double* M;     // [B][D][D]  QR input, (A L)^T in preconditioned coordinates
+  double* R;     // [B][D][D]  QR output (upper), preconditioned coordinates
+  double* J;     // [B][d][k*d] Jacobian blocks
+  double* z;     // [B][d]     residual
+  double* err;   // [B][d]     dt * sigma_hat * std (unnormalised error estimate)
+  double* Ft;    // [B][D][d]  F^T = U^- H^T, later W^T
+  double* X;     // [B][d][D]  W U^-
+  double* S;     // [B][d][d]
+  double* sig_new;  // [B]
+};
+
+void dense_launch_step(const DenseView& v, const StepArg* args, const IwpConst* K, hipStream_t s);
+void dense_launch_interp(const DenseView& v, const InterpArg* args, const IwpConst* K, hipStream_t s);
+
+}  // namespace pnode

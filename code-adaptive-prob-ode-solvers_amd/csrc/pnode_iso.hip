@@ -1,0 +1,641 @@
+// Isotropic (Kronecker) EKF0 stepping kernels for gfx950: one wavefront per trajectory.
+//
+// State per trajectory: mean (n x d) and ONE n x n factor R with Sigma = (R^T R) (x) I_d
+// (impl.select("isotropic"), /root/reference/src/odecheckpts/ivpsolvers.py:32-33). The n x n
+// algebra (IWP transition, Givens square-root time update, backward transition of the fixed-point
+// smoother, gain) is wave-uniform and lives in registers; the d-dimensional part (mean, residual,
+// error norm) is spread over the 64 lanes with wave-level reductions. The whole attempted step —
+// extrapolate, evaluate the vector field, calibrate, correct, normalise the error — is ONE kernel.
+//
+// Follows (arithmetic re-derived, see oracle/pn_oracle.py for the CPU restatement):
+//   correction_ts0 + strategy_filter/fixedpoint + solver[_dynamic]   ivpsolvers.py:37-50
+//   experiments/4_brusselator/run.py:51-61 (the configuration of the golden vectors)
+#include "pnode_device.hpp"
+
+namespace pnode {
+
+// ---------------------------------------------------------------------------------------------
+// Small (n x n) pieces, all wave-uniform
+// ---------------------------------------------------------------------------------------------
+
+// Time update in preconditioned coordinates.
+//   in : Rprev (Sigma_prev = Rprev^T Rprev, plain coordinates), p/pinv for this dt, sigma
+//   out: Rm   (Sigma^- = Rm^T Rm, plain coordinates, upper triangular)
+//        if COND: G (n x n, plain coordinates) and RL (upper, Lambda = RL^T RL) of the backward
+//        transition  x_prev | x_new ~ N(G x_new + xi, Lambda)
+template <int N, bool COND>
+__device__ __forceinline__ void iso_time_update(const IwpConst& K, const double (&Rprev)[N][N], const double (&p)[N],
+                                                const double (&pinv)[N], double sigma, double (&Rm)[N][N],
+                                                double (&G)[N][N], double (&RL)[N][N]) {
+  double Bm[N][N];  // Rprev * diag(pinv)
+  double M[N][N];   // Bm * Abar^T  = (Abar Ltilde)^T
+#pragma unroll
+  for (int c = 0; c < N; ++c)
+#pragma unroll
+    for (int i = 0; i < N; ++i) Bm[c][i] = Rprev[c][i] * pinv[i];
+#pragma unroll
+  for (int c = 0; c < N; ++c)
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      double acc = 0.0;
+#pragma unroll
+      for (int k = i; k < N; ++k) acc += Bm[c][k] * K.a[i][k];
+      M[c][i] = acc;
+    }
+  double R[N][N];
+#pragma unroll
+  for (int c = 0; c < N; ++c)
+#pragma unroll
+    for (int i = 0; i < N; ++i) R[c][i] = (i >= c) ? sigma * K.qsT[c][i] : 0.0;
+#pragma unroll
+  for (int c = 0; c < N; ++c) {
+    double x[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = M[c][i];
+    givens_rotate_in<N>(R, x);
+  }
+  if constexpr (COND) {
+    // cross = Sigma~ Abar^T = Bm^T M ;  Gp = cross (R^T R)^{-1}
+    double Gp[N][N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      double row[N];
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        double acc = 0.0;
+#pragma unroll
+        for (int c = 0; c < N; ++c) acc += Bm[c][i] * M[c][j];
+        row[j] = acc;
+      }
+      // y R = row  (R upper: forward over columns)
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        double acc = row[j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) acc -= row[k] * R[k][j];
+        row[j] = (R[j][j] != 0.0) ? acc / R[j][j] : 0.0;  // pseudo-inverse on an exactly singular factor
+      }
+      // x R^T = y  (backward)
+#pragma unroll
+      for (int j = N - 1; j >= 0; --j) {
+        double acc = row[j];
+#pragma unroll
+        for (int k = j + 1; k < N; ++k) acc -= row[k] * R[j][k];
+        row[j] = (R[j][j] != 0.0) ? acc / R[j][j] : 0.0;
+      }
+#pragma unroll
+      for (int j = 0; j < N; ++j) Gp[i][j] = row[j];
+    }
+    // Lambda (Joseph form, square-root): rows of Bm (I - Gp Abar)^T and sigma*qsT*Gp^T
+    double T[N][N];
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        double acc = (i == k) ? 1.0 : 0.0;
+#pragma unroll
+        for (int j = 0; j <= k; ++j) acc -= Gp[i][j] * K.a[j][k];
+        T[i][k] = acc;
+      }
+#pragma unroll
+    for (int c = 0; c < N; ++c)
+#pragma unroll
+      for (int i = 0; i < N; ++i) RL[c][i] = 0.0;
+#pragma unroll
+    for (int c = 0; c < N; ++c) {
+      double x[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) acc += Bm[c][k] * T[i][k];
+        x[i] = acc;
+      }
+      givens_rotate_in<N>(RL, x);
+    }
+#pragma unroll
+    for (int c = 0; c < N; ++c) {
+      double x[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = c; k < N; ++k) acc += K.qsT[c][k] * Gp[i][k];
+        x[i] = sigma * acc;
+      }
+      givens_rotate_in<N>(RL, x);
+    }
+    // back to plain coordinates
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        G[i][j] = p[i] * Gp[i][j] * pinv[j];
+        RL[i][j] *= p[j];
+      }
+  }
+#pragma unroll
+  for (int c = 0; c < N; ++c)
+#pragma unroll
+    for (int i = 0; i < N; ++i) Rm[c][i] = R[c][i] * p[i];
+}
+
+// Compose  x_ckpt | x_prev ~ (G0, xi0, RL0)  with  x_prev | x_new ~ (G, xi, RL):
+//   G <- G0 G ;  RL <- qr_r([RL G0^T ; RL0])   (xi is handled per lane by the caller)
+template <int N>
+__device__ __forceinline__ void iso_merge_small(const double (&G0)[N][N], const double (&RL0)[N][N], double (&G)[N][N],
+                                                double (&RL)[N][N]) {
+  double Rn[N][N];
+#pragma unroll
+  for (int c = 0; c < N; ++c)
+#pragma unroll
+    for (int i = 0; i < N; ++i) Rn[c][i] = (i >= c) ? RL0[c][i] : 0.0;
+#pragma unroll
+  for (int c = 0; c < N; ++c) {
+    double x[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      double acc = 0.0;
+#pragma unroll
+      for (int k = 0; k < N; ++k) acc += RL[c][k] * G0[i][k];
+      x[i] = acc;
+    }
+    givens_rotate_in<N>(Rn, x);
+  }
+  double Gn[N][N];
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      double acc = 0.0;
+#pragma unroll
+      for (int k = 0; k < N; ++k) acc += G0[i][k] * G[k][j];
+      Gn[i][j] = acc;
+    }
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      G[i][j] = Gn[i][j];
+      RL[i][j] = Rn[i][j];
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void load_small(const double* __restrict__ src, double (&dst)[N][N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int j = 0; j < N; ++j) dst[i][j] = src[i * N + j];
+}
+template <int N>
+__device__ __forceinline__ void store_small(double* __restrict__ dst, const double (&src)[N][N], int lane) {
+  // wave-uniform data: let lane (i*N + j) % 64 write element (i, j)
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+      if (((i * N + j) & 63) == lane) dst[i * N + j] = src[i][j];
+}
+
+// ---------------------------------------------------------------------------------------------
+// The fused attempted step
+// ---------------------------------------------------------------------------------------------
+
+template <int N, bool FP>
+__global__ __launch_bounds__(256) void iso_step_kernel(IsoView v, const StepArg* __restrict__ args,
+                                                       const IwpConst* __restrict__ Kc) {
+  extern __shared__ double smem[];
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const int b = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv);
+  if (b >= v.B) return;
+  const StepArg arg = args[b];
+  if (!arg.active) return;
+  const IwpConst& K = *Kc;
+  const int d = v.d, k = v.k;
+  double* ybuf = smem + size_t(wv) * (size_t(k) + 1) * d;  // [k][d] staged state for the vector field
+  double* zbuf = ybuf + size_t(k) * d;                     // [d] residual
+
+  const double dt = arg.dt;
+  double p[N], pinv[N];
+  preconditioner<N>(dt, K, p, pinv);
+
+  const size_t sB = size_t(v.B);
+  const double* msrc = v.mean + (size_t(arg.src) * sB + b) * N * d;
+  double* mdst = v.mean + (size_t(arg.dst) * sB + b) * N * d;
+
+  // --- pass A: mean extrapolation  m^- = P Abar P^{-1} m
+  for (int j = lane; j < d; j += kWave) {
+    double mp[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) mp[i] = pinv[i] * msrc[i * d + j];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      double acc = 0.0;
+#pragma unroll
+      for (int kk = i; kk < N; ++kk) acc += K.a[i][kk] * mp[kk];
+      const double e = p[i] * acc;
+      mdst[i * d + j] = e;
+      if (i < k) ybuf[i * d + j] = e;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0);  // LDS writes of this wave visible to all its lanes
+
+  // --- pass B: residual z = m^-[k] - f(m^-[<k])  and its norm
+  VfCtx ctx{v.vf_id, d, k, v.prm ? v.prm + (v.prm_per_traj ? size_t(b) * v.P : 0) : nullptr};
+  const double tnew = arg.t + dt;
+  double zz = 0.0;
+  for (int j = lane; j < d; j += kWave) {
+    const double z = mdst[k * d + j] - vf_f(ctx, ybuf, j, tnew);
+    zbuf[j] = z;
+    zz += z * z;
+  }
+  zz = wave_sum(zz);
+
+  // --- calibration + error estimate (isotropic EKF0: S1 = s1^2, s1 = p_k * sqrt(Qbar_kk))
+  const double s1 = p[k] * K.qdiag_sqrt[k];
+  const double sigma_hat = sqrt(zz) / (s1 * sqrt(double(d)));
+  const double err = dt * sigma_hat * s1;
+  const double sigma_prev = v.sigma[size_t(arg.src) * sB + b];
+  const double sigma = v.dynamic ? sigma_hat : sigma_prev;
+
+  // --- n x n square-root time update (+ backward transition for the fixed-point smoother)
+  double Rprev[N][N], Rm[N][N], G[N][N], RL[N][N];
+  load_small<N>(v.fac + (size_t(arg.src) * sB + b) * N * N, Rprev);
+  iso_time_update<N, FP>(K, Rprev, p, pinv, sigma, Rm, G, RL);
+
+  if constexpr (FP) {
+    // xi = m - G m^-, merged with the running backward transition of the source slot
+    double G0[N][N], RL0[N][N];
+    load_small<N>(v.cG + (size_t(arg.src) * sB + b) * N * N, G0);
+    load_small<N>(v.cLam + (size_t(arg.src) * sB + b) * N * N, RL0);
+    const double* xi0 = v.cxi + (size_t(arg.src) * sB + b) * N * d;
+    double* xid = v.cxi + (size_t(arg.dst) * sB + b) * N * d;
+    for (int j = lane; j < d; j += kWave) {
+      double xi[N], me[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) me[i] = mdst[i * d + j];
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        double acc = msrc[i * d + j];
+#pragma unroll
+        for (int kk = 0; kk < N; ++kk) acc -= G[i][kk] * me[kk];
+        xi[i] = acc;
+      }
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        double acc = xi0[i * d + j];
+#pragma unroll
+        for (int kk = 0; kk < N; ++kk) acc += G0[i][kk] * xi[kk];
+        xid[i * d + j] = acc;
+      }
+    }
+    iso_merge_small<N>(G0, RL0, G, RL);
+    store_small<N>(v.cG + (size_t(arg.dst) * sB + b) * N * N, G, lane);
+    store_small<N>(v.cLam + (size_t(arg.dst) * sB + b) * N * N, RL, lane);
+  }
+
+  // --- correction on z = 0: F = row k of L^- = column k of Rm; gain; projector-form update
+  double F[N], gain[N];
+  double s2 = 0.0;
+#pragma unroll
+  for (int c = 0; c < N; ++c) {
+    F[c] = Rm[c][k];
+    s2 += F[c] * F[c];
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    double acc = 0.0;
+#pragma unroll
+    for (int c = 0; c < N; ++c) acc += Rm[c][i] * F[c];
+    gain[i] = acc / s2;
+  }
+#pragma unroll
+  for (int c = 0; c < N; ++c)
+#pragma unroll
+    for (int i = 0; i < N; ++i) Rm[c][i] -= F[c] * gain[i];
+  store_small<N>(v.fac + (size_t(arg.dst) * sB + b) * N * N, Rm, lane);
+
+  // --- pass C: corrected mean + normalised error norm
+  const double atol = v.atol[b], rtol = v.rtol[b];
+  double acc2 = 0.0;
+  for (int j = lane; j < d; j += kWave) {
+    const double z = zbuf[j];
+    double u0 = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const double mnew = mdst[i * d + j] - gain[i] * z;
+      mdst[i * d + j] = mnew;
+      if (i == 0) u0 = mnew;
+    }
+    const double rel = err / (atol + rtol * fabs(u0));
+    acc2 += rel * rel;
+  }
+  acc2 = wave_sum(acc2);
+  if (lane == 0) {
+    v.errnorm[b] = sqrt(acc2 / double(d));
+    v.sigma[size_t(arg.dst) * sB + b] = sigma;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Checkpoint interpolation (probdiffeq "interpolate" for filter / fixedpoint) and right corner
+// ---------------------------------------------------------------------------------------------
+
+template <int N, bool FP>
+__global__ __launch_bounds__(256) void iso_interp_kernel(IsoView v, const InterpArg* __restrict__ args,
+                                                         const IwpConst* __restrict__ Kc) {
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const int b = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv);
+  if (b >= v.B) return;
+  const InterpArg arg = args[b];
+  if (arg.ckpt < 0) return;
+  const IwpConst& K = *Kc;
+  const int d = v.d;
+  const size_t sB = size_t(v.B);
+  const size_t ck = size_t(b) * v.K + arg.ckpt;
+  double* m0 = v.mean + (size_t(arg.s0) * sB + b) * N * d;
+  double* m1 = v.mean + (size_t(arg.s1) * sB + b) * N * d;
+  double* cm = v.ck_mean + ck * N * d;
+
+  if (arg.at_step) {
+    // checkpoint coincides with STEP_FROM: store it; fixedpoint resets the backward transition
+    for (int j = lane; j < d; j += kWave)
+#pragma unroll
+      for (int i = 0; i < N; ++i) cm[i * d + j] = m1[i * d + j];
+    double R1[N][N];
+    load_small<N>(v.fac + (size_t(arg.s1) * sB + b) * N * N, R1);
+    store_small<N>(v.ck_fac + ck * N * N, R1, lane);
+    if constexpr (FP) {
+      double G1[N][N], L1[N][N];
+      load_small<N>(v.cG + (size_t(arg.s1) * sB + b) * N * N, G1);
+      load_small<N>(v.cLam + (size_t(arg.s1) * sB + b) * N * N, L1);
+      store_small<N>(v.ck_G + ck * N * N, G1, lane);
+      store_small<N>(v.ck_Lam + ck * N * N, L1, lane);
+      double* xi1 = v.cxi + (size_t(arg.s1) * sB + b) * N * d;
+      double* cxi = v.ck_xi + ck * N * d;
+      for (int j = lane; j < d; j += kWave)
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+          cxi[i * d + j] = xi1[i * d + j];
+          xi1[i * d + j] = 0.0;
+        }
+#pragma unroll
+      for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+          G1[i][j] = (i == j) ? 1.0 : 0.0;
+          L1[i][j] = 0.0;
+        }
+      store_small<N>(v.cG + (size_t(arg.s1) * sB + b) * N * N, G1, lane);
+      store_small<N>(v.cLam + (size_t(arg.s1) * sB + b) * N * N, L1, lane);
+    }
+    if (lane == 0) v.ck_steps[ck] = arg.steps;
+    return;
+  }
+
+  const double sigma = v.sigma[size_t(arg.s1) * sB + b];
+  const double dt0 = arg.t - arg.t0, dt1 = arg.t1 - arg.t;
+  double p[N], pinv[N], q[N], qinv[N];
+  preconditioner<N>(dt0, K, p, pinv);
+  preconditioner<N>(dt1, K, q, qinv);
+
+  double R0[N][N], Rt[N][N], Gt[N][N], RLt[N][N];
+  load_small<N>(v.fac + (size_t(arg.s0) * sB + b) * N * N, R0);
+  iso_time_update<N, FP>(K, R0, p, pinv, sigma, Rt, Gt, RLt);
+
+  if constexpr (!FP) {
+    // filter: the solution at t is the prediction from INTERP_FROM; it becomes the new INTERP_FROM
+    for (int j = lane; j < d; j += kWave) {
+      double mp[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) mp[i] = pinv[i] * m0[i * d + j];
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        double acc = 0.0;
+#pragma unroll
+        for (int kk = i; kk < N; ++kk) acc += K.a[i][kk] * mp[kk];
+        const double e = p[i] * acc;
+        m0[i * d + j] = e;
+        cm[i * d + j] = e;
+      }
+    }
+    store_small<N>(v.fac + (size_t(arg.s0) * sB + b) * N * N, Rt, lane);
+    store_small<N>(v.ck_fac + ck * N * N, Rt, lane);
+    if (lane == 0) {
+      v.sigma[size_t(arg.s0) * sB + b] = sigma;
+      v.ck_steps[ck] = arg.steps;
+    }
+    return;
+  } else {
+    // fixedpoint: (i) t0 -> t with merged backward transition, (ii) t -> t1 from an identity
+    // transition, (iii) marginalise STEP_FROM through the t1 -> t transition.
+    double Runused[N][N], G1[N][N], RL1[N][N];
+    iso_time_update<N, true>(K, Rt, q, qinv, sigma, Runused, G1, RL1);
+
+    double G0[N][N], RL0[N][N];
+    load_small<N>(v.cG + (size_t(arg.s0) * sB + b) * N * N, G0);
+    load_small<N>(v.cLam + (size_t(arg.s0) * sB + b) * N * N, RL0);
+    double* xi0 = v.cxi + (size_t(arg.s0) * sB + b) * N * d;
+    double* xi1 = v.cxi + (size_t(arg.s1) * sB + b) * N * d;
+    double* cxi = v.ck_xi + ck * N * d;
+    for (int j = lane; j < d; j += kWave) {
+      double mo[N], mt[N], mt1[N], tmp[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        mo[i] = m0[i * d + j];
+        tmp[i] = pinv[i] * mo[i];
+      }
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        double acc = 0.0;
+#pragma unroll
+        for (int kk = i; kk < N; ++kk) acc += K.a[i][kk] * tmp[kk];
+        mt[i] = p[i] * acc;  // filtering mean at t
+      }
+#pragma unroll
+      for (int i = 0; i < N; ++i) tmp[i] = qinv[i] * mt[i];
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        double acc = 0.0;
+#pragma unroll
+        for (int kk = i; kk < N; ++kk) acc += K.a[i][kk] * tmp[kk];
+        mt1[i] = q[i] * acc;  // prediction of t1 from t
+      }
+      // xi of (t0 -> t), merged with the running transition of INTERP_FROM
+      double xit[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        double acc = mo[i];
+#pragma unroll
+        for (int kk = 0; kk < N; ++kk) acc -= Gt[i][kk] * mt[kk];
+        xit[i] = acc;
+      }
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        double acc = xi0[i * d + j];
+#pragma unroll
+        for (int kk = 0; kk < N; ++kk) acc += G0[i][kk] * xit[kk];
+        cxi[i * d + j] = acc;
+      }
+      // xi of (t -> t1); smoothed mean at t
+      double m1v[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) m1v[i] = m1[i * d + j];
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        double x1 = mt[i], ms = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < N; ++kk) {
+          x1 -= G1[i][kk] * mt1[kk];
+          ms += G1[i][kk] * m1v[kk];
+        }
+        xi1[i * d + j] = x1;         // STEP_FROM now remembers how to get back to t
+        cm[i * d + j] = ms + x1;     // solution at the checkpoint
+        m0[i * d + j] = mt[i];       // INTERP_FROM <- filtering state at t
+        xi0[i * d + j] = 0.0;        //   ... with an identity backward transition
+      }
+    }
+    // checkpoint factor: qr_r([R1 G1^T ; RL1])
+    double R1[N][N], Rs[N][N];
+    load_small<N>(v.fac + (size_t(arg.s1) * sB + b) * N * N, R1);
+#pragma unroll
+    for (int c = 0; c < N; ++c)
+#pragma unroll
+      for (int i = 0; i < N; ++i) Rs[c][i] = (i >= c) ? RL1[c][i] : 0.0;
+#pragma unroll
+    for (int c = 0; c < N; ++c) {
+      double x[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        double acc = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < N; ++kk) acc += R1[c][kk] * G1[i][kk];
+        x[i] = acc;
+      }
+      givens_rotate_in<N>(Rs, x);
+    }
+    store_small<N>(v.ck_fac + ck * N * N, Rs, lane);
+    // checkpoint backward transition = merged (t0 -> t) transition
+    iso_merge_small<N>(G0, RL0, Gt, RLt);
+    store_small<N>(v.ck_G + ck * N * N, Gt, lane);
+    store_small<N>(v.ck_Lam + ck * N * N, RLt, lane);
+    // STEP_FROM transition <- (t1 -> t); INTERP_FROM <- (filter state at t, identity)
+    store_small<N>(v.cG + (size_t(arg.s1) * sB + b) * N * N, G1, lane);
+    store_small<N>(v.cLam + (size_t(arg.s1) * sB + b) * N * N, RL1, lane);
+    store_small<N>(v.fac + (size_t(arg.s0) * sB + b) * N * N, Rt, lane);
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        G0[i][j] = (i == j) ? 1.0 : 0.0;
+        RL0[i][j] = 0.0;
+      }
+    store_small<N>(v.cG + (size_t(arg.s0) * sB + b) * N * N, G0, lane);
+    store_small<N>(v.cLam + (size_t(arg.s0) * sB + b) * N * N, RL0, lane);
+    if (lane == 0) {
+      v.sigma[size_t(arg.s0) * sB + b] = sigma;
+      v.ck_steps[ck] = arg.steps;
+    }
+  }
+}
+
+// Backward pass over the stored checkpoint transitions (stats.markov_marginals(reverse=True),
+// /root/reference/src/odecheckpts/ivpsolvers.py:80-81). out: [B][K+1][n][d]; out[:, c+1] is the
+// smoothed mean at checkpoint c, out[:, 0] the smoothed mean at the initial time.
+template <int N>
+__global__ __launch_bounds__(256) void iso_smooth_kernel(IsoView v, const int32_t* __restrict__ num_filled,
+                                                         double* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const int b = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv);
+  if (b >= v.B) return;
+  const int nf = num_filled[b];
+  if (nf <= 0) return;
+  const int d = v.d;
+  double* ob = out + size_t(b) * (v.K + 1) * N * d;
+  for (int j = lane; j < d; j += kWave) {
+    double m[N];
+    const double* last = v.ck_mean + (size_t(b) * v.K + (nf - 1)) * N * d;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      m[i] = last[i * d + j];
+      ob[size_t(nf) * N * d + i * d + j] = m[i];
+    }
+    for (int c = nf - 1; c >= 0; --c) {
+      const double* Gc = v.ck_G + (size_t(b) * v.K + c) * N * N;
+      const double* xc = v.ck_xi + (size_t(b) * v.K + c) * N * d;
+      double mn[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        double acc = xc[i * d + j];
+#pragma unroll
+        for (int kk = 0; kk < N; ++kk) acc += Gc[i * N + kk] * m[kk];
+        mn[i] = acc;
+      }
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        m[i] = mn[i];
+        ob[size_t(c) * N * d + i * d + j] = mn[i];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host-side launchers (dispatch on n = nu + 1 and strategy)
+// ---------------------------------------------------------------------------------------------
+
+template <int N>
+static void launch_step_n(const IsoView& v, const StepArg* args, const IwpConst* K, hipStream_t s) {
+  const int blocks = (v.B + 3) / 4;
+  const size_t shm = size_t(4) * (size_t(v.k) + 1) * v.d * sizeof(double);
+  if (v.fixedpoint)
+    hipLaunchKernelGGL((iso_step_kernel<N, true>), dim3(blocks), dim3(256), shm, s, v, args, K);
+  else
+    hipLaunchKernelGGL((iso_step_kernel<N, false>), dim3(blocks), dim3(256), shm, s, v, args, K);
+}
+template <int N>
+static void launch_interp_n(const IsoView& v, const InterpArg* args, const IwpConst* K, hipStream_t s) {
+  const int blocks = (v.B + 3) / 4;
+  if (v.fixedpoint)
+    hipLaunchKernelGGL((iso_interp_kernel<N, true>), dim3(blocks), dim3(256), 0, s, v, args, K);
+  else
+    hipLaunchKernelGGL((iso_interp_kernel<N, false>), dim3(blocks), dim3(256), 0, s, v, args, K);
+}
+
+#define PNODE_DISPATCH_N(n, CALL)      \
+  switch (n) {                         \
+    case 2: CALL(2); break;            \
+    case 3: CALL(3); break;            \
+    case 4: CALL(4); break;            \
+    case 5: CALL(5); break;            \
+    case 6: CALL(6); break;            \
+    case 7: CALL(7); break;            \
+    case 8: CALL(8); break;            \
+    case 9: CALL(9); break;            \
+    default: break;                    \
+  }
+
+void iso_launch_step(const IsoView& v, const StepArg* args, const IwpConst* K, hipStream_t s) {
+#define CALL(NN) launch_step_n<NN>(v, args, K, s)
+  PNODE_DISPATCH_N(v.n, CALL)
+#undef CALL
+}
+void iso_launch_interp(const IsoView& v, const InterpArg* args, const IwpConst* K, hipStream_t s) {
+#define CALL(NN) launch_interp_n<NN>(v, args, K, s)
+  PNODE_DISPATCH_N(v.n, CALL)
+#undef CALL
+}
+void iso_launch_smooth(const IsoView& v, const int32_t* num_filled, double* out, hipStream_t s) {
+  const int blocks = (v.B + 3) / 4;
+#define CALL(NN) hipLaunchKernelGGL((iso_smooth_kernel<NN>), dim3(blocks), dim3(256), 0, s, v, num_filled, out)
+  PNODE_DISPATCH_N(v.n, CALL)
+#undef CALL
+}
+
+}  // namespace pnode

@@ -1,0 +1,311 @@
+"""Adaptive and fixed-grid IVP solution routines (probdiffeq.ivpsolve surface) for batches of IVPs.
+
+Reference call sites: control_proportional_integral / adaptive (src/odecheckpts/ivpsolvers.py:52-53),
+solve_adaptive_save_at (ivpsolvers.py:71-77, experiments/4_brusselator/run.py:122-129),
+solve_adaptive_terminal_values (run.py:82-90), solve_adaptive_save_every_step and solve_fixed_grid
+(experiments/1_van_der_pol/vdp.py:77-79,90).
+
+Division of labour (BASELINE north star): the predict/correct step, the error norm and the checkpoint
+interpolation run on the GPU for the whole batch at once; the PI step-size controller, the
+accept/reject decision and the save_at cursor stay HERE, sequential per trajectory, vectorised over the
+batch with NumPy. One host<->device round trip per attempted batched step.
+"""
+
+from __future__ import annotations
+
+import dataclasses
+import warnings
+
+import numpy as np
+
+from . import _backend
+from .ivpsolvers import InitialCondition, Solver
+from .vector_fields import VectorField
+
+
+@dataclasses.dataclass(frozen=True)
+class PIControl:
+    """Proportional-integral step-size control, same defaults as the reference's controller."""
+
+    clip: bool = False
+    safety: float = 0.95
+    factor_min: float = 0.2
+    factor_max: float = 10.0
+    power_integral_unscaled: float = 0.3
+    power_proportional_unscaled: float = 0.4
+
+    def apply(self, dt, err_prev, err, rate):
+        """Vectorised over the batch; `err` is the normalised error of the attempt just made."""
+        with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+            a1 = (1.0 / err) ** (self.power_integral_unscaled / rate)
+            a2 = (err_prev / err) ** (self.power_proportional_unscaled / rate)
+            factor = np.maximum(self.factor_min, np.minimum(self.safety * a1 * a2, self.factor_max))
+        err_prev_new = np.where(err <= 1.0, err, err_prev)
+        return factor * dt, err_prev_new
+
+
+def control_proportional_integral(*, clip=False, safety=0.95, factor_min=0.2, factor_max=10.0,
+                                  power_integral_unscaled=0.3, power_proportional_unscaled=0.4) -> PIControl:
+    return PIControl(clip, safety, factor_min, factor_max, power_integral_unscaled, power_proportional_unscaled)
+
+
+@dataclasses.dataclass(frozen=True)
+class AdaptiveSolver:
+    solver: Solver
+    atol: object
+    rtol: object
+    control: PIControl
+    numerical_zero: float = 1e-10
+
+
+def adaptive(solver: Solver, atol=1e-4, rtol=1e-2, control=None, norm_ord=None, numerical_zero=1e-10):
+    """atol / rtol may be scalars or arrays of shape (batch,): a tolerance sweep is a batch."""
+    if norm_ord is not None:
+        raise ValueError("only the default (RMS) error norm is implemented")
+    if control is None:
+        control = control_proportional_integral()
+    return AdaptiveSolver(solver, atol, rtol, control, numerical_zero)
+
+
+@dataclasses.dataclass
+class Posterior:
+    """Means of the posterior at the returned time points (+ the live device batch for more reads)."""
+
+    means: np.ndarray  # (B, T, n, d)
+    kind: str  # "filter" | "fixedpoint"
+    batch: object = None
+
+
+@dataclasses.dataclass
+class Solution:
+    t: np.ndarray
+    u: np.ndarray
+    posterior: Posterior
+    output_scale: np.ndarray
+    num_steps: np.ndarray
+    num_attempts: np.ndarray = None
+
+
+def _as_vf(vf) -> VectorField:
+    if not isinstance(vf, VectorField):
+        raise TypeError(
+            "vector_field must be a probdiffeq_hip.vector_fields.VectorField (device code + analytic "
+            "Jacobian selected by id); arbitrary Python callables cannot run inside the HIP step kernel."
+        )
+    return vf
+
+
+def _make_batch(vf, init: InitialCondition, solver: Solver, num_checkpoints, device=None):
+    vf = _as_vf(vf)
+    st = solver.strategy
+    B, n, d = init.tcoeffs.shape
+    if n != st.prior.num_derivatives + 1:
+        raise ValueError("initial condition does not match the prior's number of derivatives")
+    if d != vf.d or st.correction.ode_order != vf.ode_order:
+        raise ValueError(f"vector field {vf.name!r} has d={vf.d}, order={vf.ode_order}; solver was built for "
+                         f"d={d}, order={st.correction.ode_order}")
+    if st.ode_shape not in ((), (d,)):
+        raise ValueError(f"impl.select ode_shape {st.ode_shape} does not match the initial condition (d={d})")
+    if st.kind == "smoother":
+        raise NotImplementedError("strategy_smoother (O(#steps) memory) is outside the hot-path scope; "
+                                  "use strategy_fixedpoint with solve_adaptive_save_at")
+    prm = vf.param_array()
+    batch = _backend.Batch(
+        batch=B, d=d, nu=st.prior.num_derivatives, ode_order=st.correction.ode_order, model=st.model,
+        correction=st.correction.kind, strategy=st.kind, calibration=solver.calibration, vf_id=vf.vf_id,
+        vf_params=prm, num_checkpoints=num_checkpoints, device=device,
+    )
+    return batch
+
+
+class _AdaptiveLoop:
+    """Host-sequential controller state for one batch."""
+
+    def __init__(self, batch, asolver: AdaptiveSolver, t0, dt0):
+        B = batch.B
+        self.batch = batch
+        self.ctrl = asolver.control
+        self.rate = asolver.solver.error_contraction_rate
+        self.nz = asolver.numerical_zero
+        self.t = np.array(np.broadcast_to(t0, (B,)), dtype=np.float64)
+        self.t_prev = self.t.copy()
+        self.dt = np.array(np.broadcast_to(dt0, (B,)), dtype=np.float64)
+        self.err_prev = np.ones(B)
+        self.steps = np.zeros(B, dtype=np.int64)
+        self.attempts = np.zeros(B, dtype=np.int64)
+        self.failed = np.zeros(B, dtype=bool)
+        self._err = np.zeros(B)
+        self.device_ms = 0.0
+        self.num_launches = 0
+
+    def attempt(self, active, t1=None):
+        """One batched attempted step for the trajectories in `active`; returns the accept mask."""
+        dt = self.dt
+        if self.ctrl.clip and t1 is not None:
+            dt = np.where(active, np.minimum(dt, t1 - self.t), dt)
+        dt_used = np.where(active, dt, 1.0)
+        err = self.batch.attempt_step(dt_used, active, self._err)
+        self.device_ms += self.batch.last_step_ms()
+        self.num_launches += 1
+        self.attempts += active
+        new_dt, new_prev = self.ctrl.apply(dt_used, self.err_prev, err, self.rate)
+        # the reference's rejection loop runs `while error_norm > 1`: a NaN error leaves the loop
+        accept = active & ~(err > 1.0)
+        self.dt = np.where(active, new_dt, self.dt)
+        self.err_prev = np.where(active, new_prev, self.err_prev)
+        self.batch.commit(accept)
+        self.t_prev = np.where(accept, self.t, self.t_prev)
+        self.t = np.where(accept, self.t + dt_used, self.t)
+        self.steps += accept
+        bad = active & ~(np.isfinite(self.dt) & np.isfinite(self.t) & (self.dt > 0))
+        self.failed |= bad
+        return accept
+
+
+def _finish(sol_means, init, kind, batch, t, num_steps, loop, squeeze):
+    u = sol_means[:, :, 0, :]
+    out_scale = batch.read_output_scale(0)
+    post = Posterior(sol_means, kind, batch)
+    if squeeze:
+        return Solution(t if t.ndim == 1 else t[0], u[0], post, out_scale[0], num_steps[0], loop.attempts[0])
+    return Solution(t, u, post, out_scale, num_steps, loop.attempts.copy())
+
+
+def solve_adaptive_save_at(vector_field, initial_condition: InitialCondition, save_at, adaptive_solver: AdaptiveSolver,
+                           dt0, *, device=None) -> Solution:
+    """Adaptive solve that stores the solution at `save_at` only (fixed memory, O(len(save_at))).
+
+    save_at: (K+1,) shared or (B, K+1) per trajectory; save_at[..., 0] is the initial time. Steps are
+    not clipped (unless control.clip): an accepted step that oversteps a checkpoint is interpolated.
+    With strategy_fixedpoint, `Solution.u` holds the smoothed means (backward pass over the stored
+    checkpoint transitions), as probdiffeq's solution object does.
+    """
+    solver = adaptive_solver.solver
+    if not solver.strategy.is_suitable_for_save_at:
+        warnings.warn("strategy is not suitable for save_at", stacklevel=2)
+    init = initial_condition
+    B, n, d = init.tcoeffs.shape
+    sa = np.asarray(save_at, dtype=np.float64)
+    sa_b = np.ascontiguousarray(np.broadcast_to(sa, (B, sa.shape[-1])))
+    K = sa_b.shape[1] - 1
+    if K < 1 or np.any(np.diff(sa_b, axis=1) <= 0):
+        raise ValueError("save_at must be strictly increasing with at least two points")
+    batch = _make_batch(vector_field, init, solver, K, device)
+    batch.set_initial(init.tcoeffs, sa_b[:, 0], init.output_scale)
+    batch.set_tolerances(adaptive_solver.atol, adaptive_solver.rtol)
+    loop = _AdaptiveLoop(batch, adaptive_solver, sa_b[:, 0], dt0)
+    nz = adaptive_solver.numerical_zero
+    cursor = np.ones(B, dtype=np.int64)
+    num_steps = np.zeros((B, K + 1), dtype=np.int64)
+    rows = np.arange(B)
+    while True:
+        while True:
+            live = (cursor <= K) & ~loop.failed
+            nxt = sa_b[rows, np.minimum(cursor, K)]
+            pend = live & (loop.t + nz >= nxt)
+            if not pend.any():
+                break
+            over = pend & (loop.t > nxt + nz)
+            corner = pend & ~over
+            if over.any():
+                batch.interpolate(np.where(over, nxt, 0.0), np.where(over, cursor - 1, -1))
+            if corner.any():
+                batch.checkpoint_at_step(np.where(corner, cursor - 1, -1))
+            num_steps[rows[pend], cursor[pend]] = loop.steps[pend]
+            cursor = cursor + pend
+        active = (cursor <= K) & ~loop.failed
+        if not active.any():
+            break
+        t_next = sa_b[rows, np.minimum(cursor, K)]
+        loop.attempt(active, t1=t_next)
+    if solver.strategy.kind == "fixedpoint":
+        means = batch.smooth_checkpoint_means(np.minimum(cursor - 1, K))
+        # the smoothed value at t0 equals the initial mean up to rounding; keep the backward-pass value
+    else:
+        means = np.concatenate([init.tcoeffs[:, None], batch.read_checkpoint_means()], axis=1)
+    if loop.failed.any():
+        for b in np.nonzero(loop.failed)[0]:
+            means[b, cursor[b]:] = np.nan
+    return _finish(means, init, solver.strategy.kind, batch, sa if sa.ndim == 1 else sa_b, num_steps, loop,
+                   not init.batched)
+
+
+def solve_adaptive_terminal_values(vector_field, initial_condition: InitialCondition, t0, t1,
+                                   adaptive_solver: AdaptiveSolver, dt0, *, device=None) -> Solution:
+    """Adaptive solve returning only the state at t1 (experiments/4_brusselator/run.py:82-90)."""
+    B = initial_condition.tcoeffs.shape[0]
+    sa = np.stack([np.broadcast_to(np.asarray(t0, dtype=np.float64), (B,)),
+                   np.broadcast_to(np.asarray(t1, dtype=np.float64), (B,))], axis=1)
+    sol = solve_adaptive_save_at(vector_field, dataclasses.replace(initial_condition, batched=True), sa,
+                                 adaptive_solver, dt0, device=device)
+    post = Posterior(sol.posterior.means[:, -1:], sol.posterior.kind, sol.posterior.batch)
+    if not initial_condition.batched:
+        return Solution(sa[0, 1], sol.u[0, -1], post, sol.output_scale[0], sol.num_steps[0, -1], sol.num_attempts[0])
+    return Solution(sa[:, 1], sol.u[:, -1], post, sol.output_scale, sol.num_steps[:, -1], sol.num_attempts)
+
+
+def solve_adaptive_save_every_step(vector_field, initial_condition: InitialCondition, t0, t1,
+                                   adaptive_solver: AdaptiveSolver, dt0, *, device=None):
+    """Adaptive solve that returns every accepted step (vdp.py:77-79). Ragged over the batch: returns a
+    Solution for an unbatched initial condition and a list of Solutions otherwise. Meant for small
+    problems: each accepted batched step copies the means back to the host."""
+    solver = adaptive_solver.solver
+    if solver.strategy.kind != "filter":
+        raise NotImplementedError("solve_adaptive_save_every_step is implemented for strategy_filter "
+                                  "(the reference's use, vdp.py:65); use solve_adaptive_save_at with fixedpoint")
+    init = initial_condition
+    B, n, d = init.tcoeffs.shape
+    t0b = np.array(np.broadcast_to(t0, (B,)), dtype=np.float64)
+    t1b = np.array(np.broadcast_to(t1, (B,)), dtype=np.float64)
+    batch = _make_batch(vector_field, init, solver, 1, device)
+    batch.set_initial(init.tcoeffs, t0b, init.output_scale)
+    batch.set_tolerances(adaptive_solver.atol, adaptive_solver.rtol)
+    loop = _AdaptiveLoop(batch, adaptive_solver, t0b, dt0)
+    ts = [[t0b[b]] for b in range(B)]
+    ms = [[init.tcoeffs[b]] for b in range(B)]
+    while True:
+        active = (loop.t < t1b) & ~loop.failed
+        if not active.any():
+            break
+        acc = loop.attempt(active, t1=t1b)
+        inside = acc & (loop.t < t1b)
+        if inside.any():
+            means = batch.read_mean(0)
+            for b in np.nonzero(inside)[0]:
+                ts[b].append(loop.t[b])
+                ms[b].append(means[b])
+    over = (loop.t > t1b) & ~loop.failed
+    corner = ~over & ~loop.failed
+    if over.any():
+        batch.interpolate(np.where(over, t1b, 0.0), np.where(over, 0, -1))
+    if corner.any():
+        batch.checkpoint_at_step(np.where(corner, 0, -1))
+    last = batch.read_checkpoint_means()[:, 0]
+    scale = batch.read_output_scale(0)
+    sols = []
+    for b in range(B):
+        ts[b].append(t1b[b])
+        ms[b].append(last[b] if not loop.failed[b] else np.full_like(last[b], np.nan))
+        means = np.stack(ms[b])
+        sols.append(Solution(np.asarray(ts[b]), means[:, 0, :], Posterior(means[None], "filter", batch), scale[b],
+                             np.arange(len(ts[b])).clip(max=int(loop.steps[b])), int(loop.attempts[b])))
+    return sols if init.batched else sols[0]
+
+
+def solve_fixed_grid(vector_field, initial_condition: InitialCondition, grid, solver: Solver, *, device=None) -> Solution:
+    """Pure predict/correct loop on a prescribed grid, no controller (vdp.py:88-103). All launches are
+    enqueued on the device stream without host synchronisation. grid: (G,) shared or (B, G)."""
+    init = initial_condition
+    B, n, d = init.tcoeffs.shape
+    grid = np.asarray(grid, dtype=np.float64)
+    gb = np.broadcast_to(grid, (B, grid.shape[-1]))
+    batch = _make_batch(vector_field, init, solver, 0, device)
+    batch.set_initial(init.tcoeffs, np.ascontiguousarray(gb[:, 0]), init.output_scale)
+    u = batch.solve_fixed_grid(grid if grid.ndim == 1 else np.ascontiguousarray(gb))
+    G = gb.shape[1]
+    steps = np.broadcast_to(np.arange(G), (B, G))
+    post = Posterior(batch.read_mean(0)[:, None], solver.strategy.kind, batch)
+    scale = batch.read_output_scale(0)
+    if not init.batched:
+        return Solution(grid, u[0], post, scale[0], steps[0], G - 1)
+    return Solution(grid, u, post, scale, steps, np.full(B, G - 1))

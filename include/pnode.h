@@ -1,0 +1,152 @@
+/* pnode.h — C ABI of the MI355X-native EKF predict/correct stepping path.
+ *
+ * The reference (pnkraemer/code-adaptive-prob-ode-solvers) has NO native boundary: the hot path is
+ * entered through Python calls into probdiffeq (third party). This header therefore DEFINES the
+ * boundary a probdiffeq-style host binds to; each entry point cites the reference call site whose
+ * work it replaces (paths relative to /root/reference).
+ *
+ * Model: one opaque handle (`pnode_batch`) owns the device state of B independent IVPs on ONE GPU
+ * and one HIP stream. The adaptive PI controller and the save_at bookkeeping stay on the host
+ * (sequential, per trajectory); every call below moves whole batches. All host buffers are
+ * caller-owned, contiguous, C-order doubles / int32 / uint8. Every function returns 0 on success
+ * and a negative PNODE_E* code otherwise; `pnode_last_error()` has the text. A handle is not
+ * thread-safe; use one handle per GPU (per process, under torch.distributed / RCCL).
+ *
+ * State slots per trajectory (the reference carries the same three copies, experiments/
+ * 4_brusselator/run.py:68-70): STEP_FROM (latest accepted), INTERP_FROM (previous accepted or last
+ * checkpoint), PROPOSED (target of the running attempt). Checkpoint storage is separate and sized
+ * at creation (`num_checkpoints`).
+ */
+#ifndef PNODE_H
+#define PNODE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PNODE_OK 0
+#define PNODE_EINVAL (-1)   /* bad argument / unsupported configuration  -> Python ValueError   */
+#define PNODE_EDEVICE (-2)  /* HIP runtime failure                      -> Python RuntimeError */
+#define PNODE_ESTATE (-3)   /* call order violated (e.g. step before set_initial)              */
+
+/* impl.select("isotropic" | "dense", ode_shape=(d,))  — src/odecheckpts/ivpsolvers.py:32-33,
+ * experiments/1_van_der_pol/vdp.py:61 */
+#define PNODE_MODEL_ISOTROPIC 0
+#define PNODE_MODEL_DENSE 1
+/* ivpsolvers.correction_ts0 / correction_ts1 — ivpsolvers.py:37, vdp.py:64 */
+#define PNODE_CORR_TS0 0
+#define PNODE_CORR_TS1 1
+/* ivpsolvers.strategy_filter / strategy_fixedpoint — vdp.py:65, ivpsolvers.py:43 */
+#define PNODE_STRATEGY_FILTER 0
+#define PNODE_STRATEGY_FIXEDPOINT 1
+/* ivpsolvers.solver / solver_dynamic — ivpsolvers.py:45-50 */
+#define PNODE_CALIB_NONE 0
+#define PNODE_CALIB_DYNAMIC 1
+
+/* Built-in vector fields (device code + analytic Jacobians); replaces the JAX callables of
+ * src/odecheckpts/ivps.py. `vf_params` meaning per id is given on the right. */
+#define PNODE_VF_BRUSSELATOR 0   /* ivps.py:124-156; d = 2N, order 1; params: [alpha] (default 1/50) */
+#define PNODE_VF_VDP_ORDER2 1    /* ivps.py:159-167, vdp.py:52-54; d = 1, order 2; params: [mu]       */
+#define PNODE_VF_VDP_ORDER1 2    /* experiments/old/7_node/node.py:23-37; d = 2, order 1; [mu]        */
+#define PNODE_VF_RIGID_BODY 3    /* ivps.py:20-29 (diffeqzoo defaults); d = 3, order 1; [a, b, c]     */
+#define PNODE_VF_PLEIADES_ORDER2 4 /* ivps.py:66-99; d = 14, order 2; no params                       */
+#define PNODE_VF_PLEIADES_ORDER1 5 /* ivps.py:44-56; d = 28, order 1; no params                       */
+#define PNODE_VF_LOGISTIC 6      /* ivps.py:8-17 (diffeqzoo logistic); d = 1, order 1; [a, b]         */
+#define PNODE_VF_LINEAR 7        /* test problem u' = lam * u (diagonal); d arbitrary; [lam]          */
+
+#define PNODE_MAX_VF_PARAMS 8
+
+typedef struct pnode_config {
+  int32_t batch;            /* B: number of independent IVPs on this GPU                     */
+  int32_t d;                /* ODE dimension                                                 */
+  int32_t nu;               /* prior_ibm(num_derivatives=nu), 1..8                           */
+  int32_t ode_order;        /* 1 or 2                                                        */
+  int32_t model;            /* PNODE_MODEL_*                                                 */
+  int32_t correction;       /* PNODE_CORR_*                                                  */
+  int32_t strategy;         /* PNODE_STRATEGY_*                                              */
+  int32_t calibration;      /* PNODE_CALIB_*                                                 */
+  int32_t vf_id;            /* PNODE_VF_*                                                    */
+  int32_t num_vf_params;    /* doubles per trajectory in vf_params                           */
+  int32_t vf_params_per_trajectory; /* 0: vf_params is [P] shared, 1: [B][P]                 */
+  int32_t num_checkpoints;  /* capacity K of the checkpoint store (save_at points after t0)  */
+  int32_t device;           /* HIP device ordinal                                            */
+  int32_t reserved;
+  const double* vf_params;  /* host pointer, copied at creation                              */
+} pnode_config;
+
+typedef struct pnode_batch pnode_batch;
+
+const char* pnode_last_error(void);
+int pnode_version(void);
+/* Number of visible HIP devices (negative code on failure). */
+int pnode_device_count(void);
+
+/* Build the solver state for B trajectories.
+ * Replaces: impl.select + prior_ibm + correction_ts* + strategy_* + solver[_dynamic]
+ * (src/odecheckpts/ivpsolvers.py:32-50, experiments/4_brusselator/run.py:51-61, vdp.py:61-66). */
+int pnode_create(const pnode_config* cfg, pnode_batch** out);
+int pnode_destroy(pnode_batch* h);
+
+/* solver.initial_condition(tcoeffs, output_scale) — ivpsolvers.py:68, run.py:66, vdp.py:71.
+ * tcoeffs: [B][nu+1][d] exact derivatives at t0 (zero initial covariance); t0, output_scale: [B]. */
+int pnode_set_initial(pnode_batch* h, const double* tcoeffs, const double* t0, const double* output_scale);
+
+/* ivpsolve.adaptive(solver, atol=, rtol=) — ivpsolvers.py:53; per-trajectory so that tolerance
+ * sweeps (experiments/2_workprec_simple/run_simple.py:150-156) become the batch axis. */
+int pnode_set_tolerances(pnode_batch* h, const double* atol, const double* rtol);
+
+/* One attempted solver step for every active trajectory: extrapolate (IWP transition), linearise
+ * the vector field, innovation + local error estimate, dynamic calibration, square-root covariance
+ * time/measurement update, and the normalised error norm  ||dt*err / (atol + rtol*|u|)||_rms.
+ * Reads STEP_FROM, writes PROPOSED. dt, active: [B]; err_norm_out: [B] (untouched where inactive).
+ * Replaces the body of the rejection loop inside ivpsolve.solve_adaptive_* (ivpsolvers.py:71-77,
+ * run.py:82-90,122-129, vdp.py:77-79) up to — not including — the PI controller. Synchronous. */
+int pnode_attempt_step(pnode_batch* h, const double* dt, const uint8_t* active, double* err_norm_out);
+
+/* Accept/reject decision taken by the host controller: where accept[b] != 0,
+ * INTERP_FROM <- STEP_FROM, STEP_FROM <- PROPOSED (slot rotation, no copies), t += dt, steps += 1. */
+int pnode_commit(pnode_batch* h, const uint8_t* accept);
+
+/* Checkpoint handling after an overstep (probdiffeq "interpolate"): for every b with slot[b] >= 0,
+ * compute the solution at t[b] in (INTERP_FROM.t, STEP_FROM.t) and store it in checkpoint slot[b].
+ * filter: prediction from INTERP_FROM; fixedpoint: prediction + one-step smoothing, the running
+ * backward transition is stored with the checkpoint and reset (fixed-memory smoothing).
+ * Replaces the save_at branch of solve_adaptive_save_at (ivpsolvers.py:71-77, run.py:119-138). */
+int pnode_interpolate(pnode_batch* h, const double* t, const int32_t* slot);
+/* Same, for the case STEP_FROM.t == save_at point (no interpolation needed). */
+int pnode_checkpoint_at_step(pnode_batch* h, const int32_t* slot);
+
+/* Device-side replay of a prescribed grid without controller: ivpsolve.solve_fixed_grid
+ * (vdp.py:88-103). grid: [G] shared by all trajectories (grid_per_trajectory = 0) or [B][G].
+ * u_out: [B][G][d] zeroth-derivative means (u_out[:,0] = initial value). All launches are enqueued
+ * without host synchronisation. */
+int pnode_solve_fixed_grid(pnode_batch* h, const double* grid, int32_t num_grid, int32_t grid_per_trajectory,
+                           double* u_out);
+
+/* Read-back. which: 0 STEP_FROM, 1 INTERP_FROM, 2 PROPOSED. */
+int pnode_read_mean(pnode_batch* h, int32_t which, double* mean_out /* [B][nu+1][d] */);
+int pnode_read_time(pnode_batch* h, double* t_out /* [B] */, int64_t* num_steps_out /* [B] */);
+int pnode_read_output_scale(pnode_batch* h, int32_t which, double* out /* [B] */);
+/* Covariance factor of a state slot, as the upper-triangular-or-square R with Sigma = R^T R:
+ * isotropic [B][n][n], dense [B][D][D]. */
+int pnode_read_factor(pnode_batch* h, int32_t which, double* out);
+/* Checkpoint store: means [B][K][nu+1][d]; num_steps at each checkpoint [B][K]. */
+int pnode_read_checkpoint_means(pnode_batch* h, double* out);
+/* Backward pass over the stored checkpoint transitions (fixedpoint only):
+ * stats.markov_select_terminal + stats.markov_marginals(reverse=True) — ivpsolvers.py:80-81.
+ * num_filled[b] = number of checkpoints stored for trajectory b; the terminal marginal is the
+ * last stored checkpoint. out: [B][K][nu+1][d] smoothed means. */
+int pnode_smooth_checkpoint_means(pnode_batch* h, const int32_t* num_filled, double* out);
+
+/* Timing of the device work of the most recent attempt_step (HIP events on the handle's stream),
+ * in milliseconds; used by bench.py for the roofline line. */
+int pnode_last_step_ms(pnode_batch* h, float* ms_out);
+/* Raw stream handle (hipStream_t) for callers that need to order their own work after ours. */
+void* pnode_stream(pnode_batch* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PNODE_H */
