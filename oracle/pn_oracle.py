@@ -297,7 +297,7 @@ def step(cfg: SolverConfig, prob: Problem, state: State, dt: float) -> StepResul
         _identity_conditional(cfg, d) if cfg.strategy == "smoother" else None
     )
     m_ext2, l_ext, new_cond = _predict(cfg, prob, state.mean, state.chol, cond_in, dt, sigma, d, t_new)
-    assert np.array_equal(m_ext2, m_ext)
+    assert np.array_equal(m_ext2, m_ext, equal_nan=True)
 
     # correction: condition on z = 0 (noise-free)
     f = _observe_factor(cfg, prob, jac, l_ext, d)
