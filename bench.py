@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""Headline benchmark: accepted ODE steps / second, batched Brusselator N=32 (d=64), nu=3, dense EKF1,
+dynamic calibration, fp64 (BASELINE.json metric).
+
+A "step" of this benchmark is ONE batched attempted solver step: every trajectory of the batch runs
+predict -> linearise -> calibrate -> correct -> error norm on the GPU, then the host PI controller
+accepts/rejects and proposes the next step sizes. Inputs are resident in HBM before the timed region.
+`value` = accepted trajectory-steps of all ranks / wall time of the slowest rank.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu-baseline]
+Multi-GPU: launched by torch.distributed.run, one rank per GPU; the trajectories are sharded (weak
+scaling: B per GPU fixed), no data-path collective; RCCL is used only for the barrier, the MAX/SUM of
+the timings and the final gather of per-trajectory results.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(ROOT, "code-adaptive-prob-ode-solvers_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+N_SPATIAL = 32
+NU = 3
+TOL = 1e-6
+DT0 = 0.01
+FP64_PEAK_TFLOPS = 78.6  # MI355X fp64 vector = matrix peak
+HBM_PEAK_GBS = 8000.0
+
+
+def problem_batch(B, offset=0, total=None):
+    from probdiffeq_hip import taylor
+    from probdiffeq_hip import vector_fields as V
+
+    total = total or B
+    vf = V.brusselator(N_SPATIAL)
+    x = np.linspace(0.0, 1.0, N_SPATIAL)
+    phases = 2.0 * np.pi * (offset + np.arange(B)) / total
+    y0 = np.concatenate([1.0 + np.sin(2 * np.pi * x[None, :] + phases[:, None]), 3.0 * np.ones((B, N_SPATIAL))], axis=1)
+    tcs = taylor.odejet_padded_scan(vf, [y0], num=NU)
+    return vf, tcs
+
+
+def algorithmic_flops_lq(D):
+    """Row-Householder LQ of the D x 2D stack [T | Mt] with T triangular: 2 D^3 (the
+    predict QR dominates; structure-aware count of the algorithm actually run)."""
+    return 2.0 * D**3
+
+
+def cpu_baseline(seconds=15.0, sample=2):
+    """The NumPy oracle (kind 'port') on a bounded sample of the same workload, on this host's cores."""
+    import pn_oracle as po
+    from helpers import oracle_problem
+
+    vf, tcs = problem_batch(sample, 0, 1024)
+    cfg = po.SolverConfig(nu=NU, model="dense", correction="ts1", strategy="filter", calibration="dynamic")
+    acfg = po.AdaptiveConfig(TOL, TOL)
+    prob = oracle_problem(vf)
+    accepted = attempts = 0
+    t0 = time.perf_counter()
+    for b in range(sample):
+        ast = po.adaptive_init(po.initial_state(cfg, [c[b] for c in tcs], 0.0), DT0)
+        budget = seconds / sample
+        tb = time.perf_counter()
+        while time.perf_counter() - tb < budget:
+            before = ast.num_attempts
+            ast = po.rejection_loop(cfg, acfg, prob, ast, np.inf)
+            accepted += 1
+            attempts += ast.num_attempts - before
+    el = time.perf_counter() - t0
+    try:
+        from threadpoolctl import threadpool_info
+
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count()
+    return {"value": accepted / el, "unit": "accepted steps/s", "cores": int(cores), "kind": "port",
+            "sample": f"NumPy oracle (oracle/pn_oracle.py), {sample} trajectories of the same batch, "
+                      f"{accepted} accepted / {attempts} attempted steps in {el:.1f}s; host has {os.cpu_count()} cores"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=1024, help="trajectories per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--model", default="dense", choices=["dense", "isotropic"])
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+
+    from probdiffeq_hip import _backend, ivpsolve, ivpsolvers
+    from probdiffeq_hip.impl import impl
+
+    B = args.batch
+    vf, tcs = problem_batch(B, rank * B, world * B)
+    d = vf.d
+    D = (NU + 1) * d
+    dense = args.model == "dense"
+    impl.select(args.model, ode_shape=(d,))
+    corr = ivpsolvers.correction_ts1() if dense else ivpsolvers.correction_ts0()
+    solver = ivpsolvers.solver_dynamic(ivpsolvers.strategy_filter(ivpsolvers.prior_ibm(NU), corr))
+    asolver = ivpsolve.adaptive(solver, atol=TOL, rtol=TOL)
+    init = solver.initial_condition(tcs, 1.0)
+    batch = ivpsolve._make_batch(vf, init, solver, 1, device=local)
+    batch.set_initial(init.tcoeffs, np.zeros(B), init.output_scale)
+    batch.set_tolerances(TOL, TOL)
+    if dense:
+        batch.set_phase_timing(True)
+    loop = ivpsolve._AdaptiveLoop(batch, asolver, np.zeros(B), DT0)
+    active = np.ones(B, dtype=bool)
+
+    def barrier():
+        if dist is not None:
+            import torch
+
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loop.attempt(active)
+    barrier()
+    acc0 = int(loop.steps.sum())
+    loop.device_ms = 0.0
+    phase = np.zeros(4)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loop.attempt(active)
+        if dense:
+            phase += batch.last_phase_ms()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    accepted = int(loop.steps.sum()) - acc0
+    dev_ms = loop.device_ms
+
+    if dist is not None:
+        import torch
+
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        cnt = torch.tensor([accepted], dtype=torch.float64, device="cuda")
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        accepted = int(cnt.item())
+        # the path's only exchange: gather per-trajectory results (here: current state u, [B, d])
+        u_local = torch.from_numpy(batch.read_mean(0)[:, 0, :].copy()).cuda()
+        gathered = [torch.empty_like(u_local) for _ in range(world)]
+        dist.all_gather(gathered, u_local)
+
+    if rank == 0:
+        K = args.steps
+        out = {
+            "metric": "accepted ODE steps/sec (whole node), batched Brusselator N=32 nu=3 fp64",
+            "value": accepted / elapsed,
+            "unit": "accepted steps/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / K,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"Brusselator N=32 (d=64), nu=3, {'dense EKF1' if dense else 'isotropic EKF0'}, dynamic "
+                                   f"calibration, filter, tol 1e-6, dt0 0.01, y0 phase family; {B} trajectories per GPU",
+                       "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"shard{world}",
+                       "attempted_steps_per_s": B * world * K / elapsed,
+                       "device_ms_per_step": dev_ms / K},
+        }
+        if dense:
+            lq_ms = phase[2] / K
+            flops = algorithmic_flops_lq(D) * B
+            achieved = flops / (lq_ms * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None, "kernel": "dense_lq_kernel",
+                               "phase_ms": {"begin": phase[0] / K, "lq_input": phase[1] / K, "lq": phase[2] / K,
+                                            "correct": phase[3] / K}}
+        else:
+            n = NU + 1
+            byts = 2 * 8 * (n * d + n * n) * B
+            achieved = byts / (dev_ms / K * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "iso_step_kernel"}
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

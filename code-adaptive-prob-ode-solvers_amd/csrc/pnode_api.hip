@@ -90,6 +90,8 @@ struct pnode_batch {
   bool dense = false;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  PhaseEvents phase{};
+  bool phase_timing = false;
   IsoView iso{};
   DenseView dn{};
   IwpConst* dK = nullptr;
@@ -130,6 +132,8 @@ int pnode_destroy(pnode_batch* h) {
   if (h->hErr) (void)hipHostFree(h->hErr);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
+  for (auto& e : h->phase.ev)
+    if (e) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return PNODE_OK;
@@ -194,6 +198,7 @@ int pnode_create(const pnode_config* cfg, pnode_batch** out) {
   HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreate(&h->ev0));
   HIP_TRY(hipEventCreate(&h->ev1));
+  for (auto& e : h->phase.ev) HIP_TRY(hipEventCreate(&e));
   HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->hArgs), B * sizeof(StepArg)));
   HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->hIargs), B * sizeof(InterpArg)));
   HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->hErr), B * sizeof(double)));
@@ -322,7 +327,7 @@ int pnode_set_tolerances(pnode_batch* h, const double* atol, const double* rtol)
 
 static void enqueue_step(pnode_batch* h, const StepArg* dargs) {
   if (h->dense)
-    dense_launch_step(h->dn, dargs, h->dK, h->stream);
+    dense_launch_step(h->dn, dargs, h->dK, h->stream, h->phase_timing ? &h->phase : nullptr);
   else
     iso_launch_step(h->iso, dargs, h->dK, h->stream);
 }
@@ -581,6 +586,19 @@ int pnode_smooth_checkpoint_means(pnode_batch* h, const int32_t* num_filled, dou
 int pnode_last_step_ms(pnode_batch* h, float* ms_out) {
   if (!h || !ms_out) return fail(PNODE_EINVAL, "null argument");
   HIP_TRY(hipEventElapsedTime(ms_out, h->ev0, h->ev1));
+  return PNODE_OK;
+}
+
+int pnode_set_phase_timing(pnode_batch* h, int32_t enabled) {
+  if (!h) return fail(PNODE_EINVAL, "null handle");
+  h->phase_timing = enabled != 0;
+  return PNODE_OK;
+}
+
+int pnode_last_phase_ms(pnode_batch* h, float* ms_out) {
+  if (!h || !ms_out) return fail(PNODE_EINVAL, "null argument");
+  if (!h->dense || !h->phase_timing) return fail(PNODE_ESTATE, "phase timing is available for the dense model after set_phase_timing(1)");
+  for (int i = 0; i < 4; ++i) HIP_TRY(hipEventElapsedTime(ms_out + i, h->phase.ev[i], h->phase.ev[i + 1]));
   return PNODE_OK;
 }
 

@@ -355,14 +355,23 @@ __global__ __launch_bounds__(kThreads) void dense_interp_kernel(DenseView v, con
   if (threadIdx.x == 0) v.ck_steps[size_t(b) * v.K + arg.ckpt] = arg.steps;
 }
 
-void dense_launch_step(const DenseView& v, const StepArg* args, const IwpConst* K, hipStream_t s) {
+void dense_launch_step(const DenseView& v, const StepArg* args, const IwpConst* K, hipStream_t s,
+                       const PhaseEvents* ev) {
+  auto mark = [&](int i) {
+    if (ev) (void)hipEventRecord(ev->ev[i], s);
+  };
+  mark(0);
   const size_t shm_begin = (size_t(v.k) * v.d + v.d + 4 + size_t(v.n) * v.n) * sizeof(double);
   hipLaunchKernelGGL(dense_begin_kernel, dim3(v.B), dim3(kThreads), shm_begin, s, v, args, K);
+  mark(1);
   const int rows_per = v.D < 64 ? v.D : 64;
   hipLaunchKernelGGL(dense_lq_input_kernel, dim3(rows_per, v.B), dim3(kThreads), 0, s, v, args, K);
+  mark(2);
   hipLaunchKernelGGL(dense_lq_kernel, dim3(v.B), dim3(kThreads), 0, s, v, args);
+  mark(3);
   const size_t shm_corr = (size_t(v.d) + 4) * sizeof(double);
   hipLaunchKernelGGL(dense_correct_kernel, dim3(v.B), dim3(kThreads), shm_corr, s, v, args, K);
+  mark(4);
 }
 
 void dense_launch_interp(const DenseView& v, const InterpArg* args, const IwpConst* K, hipStream_t s) {

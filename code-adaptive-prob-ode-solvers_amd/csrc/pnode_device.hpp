@@ -55,7 +55,12 @@ struct DenseView {
   double* sig_new;  // [B]
 };
 
-void dense_launch_step(const DenseView& v, const StepArg* args, const IwpConst* K, hipStream_t s);
+// Optional per-phase timing of one dense step: events[0..4] bracket begin | lq_input | lq | correct.
+struct PhaseEvents {
+  hipEvent_t ev[5];
+};
+void dense_launch_step(const DenseView& v, const StepArg* args, const IwpConst* K, hipStream_t s,
+                       const PhaseEvents* ev = nullptr);
 void dense_launch_interp(const DenseView& v, const InterpArg* args, const IwpConst* K, hipStream_t s);
 
 }  // namespace pnode

@@ -23,7 +23,8 @@ SYMBOLS = (
     "pnode_last_error pnode_version pnode_device_count pnode_create pnode_destroy pnode_set_initial "
     "pnode_set_tolerances pnode_attempt_step pnode_commit pnode_interpolate pnode_checkpoint_at_step "
     "pnode_solve_fixed_grid pnode_read_mean pnode_read_time pnode_read_output_scale pnode_read_factor "
-    "pnode_read_checkpoint_means pnode_smooth_checkpoint_means pnode_last_step_ms pnode_stream"
+    "pnode_read_checkpoint_means pnode_smooth_checkpoint_means pnode_last_step_ms pnode_set_phase_timing "
+    "pnode_last_phase_ms pnode_stream"
 ).split()
 
 
@@ -87,6 +88,8 @@ def load_library():
     lib.pnode_read_checkpoint_means.argtypes = [vp, dp]
     lib.pnode_smooth_checkpoint_means.argtypes = [vp, i32p, dp]
     lib.pnode_last_step_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.pnode_set_phase_timing.argtypes = [vp, C.c_int32]
+    lib.pnode_last_phase_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.pnode_stream.argtypes = [vp]
     lib.pnode_stream.restype = vp
     for name in SYMBOLS:
@@ -235,6 +238,14 @@ class Batch:
         out = np.zeros((self.B, self.K + 1, self.n, self.d))
         _check(self._lib.pnode_smooth_checkpoint_means(self._h, nf.ctypes.data_as(C.POINTER(C.c_int32)), _dp(out)))
         return out
+
+    def set_phase_timing(self, enabled=True):
+        _check(self._lib.pnode_set_phase_timing(self._h, int(enabled)))
+
+    def last_phase_ms(self):
+        ms = (C.c_float * 4)()
+        _check(self._lib.pnode_last_phase_ms(self._h, ms))
+        return [float(x) for x in ms]
 
     def last_step_ms(self):
         ms = C.c_float()
