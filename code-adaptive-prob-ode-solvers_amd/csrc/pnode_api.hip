@@ -589,6 +589,12 @@ int pnode_last_step_ms(pnode_batch* h, float* ms_out) {
   return PNODE_OK;
 }
 
+int pnode_set_generic_path(pnode_batch* h, int32_t enabled) {
+  if (!h) return fail(PNODE_EINVAL, "null handle");
+  h->dn.force_generic = enabled != 0;
+  return PNODE_OK;
+}
+
 int pnode_set_phase_timing(pnode_batch* h, int32_t enabled) {
   if (!h) return fail(PNODE_EINVAL, "null handle");
   h->phase_timing = enabled != 0;

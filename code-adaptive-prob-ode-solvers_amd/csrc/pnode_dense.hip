@@ -127,7 +127,7 @@ __global__ __launch_bounds__(kThreads) void dense_begin_kernel(DenseView v, cons
       if (a == a2)
         for (int j = 0; j < n; ++j) acc += lq[k * n + j] * lq[k * n + j];
     } else {
-      for (int j = 0; j < n; ++j) {
+      for (int j = 0; j <= k; ++j) {  // lq is lower triangular: B_j = 0 for j > k
         const double lk = lq[k * n + j];
         for (int c = 0; c < d; ++c) {
           double ba = (a == c) ? lk : 0.0, ba2 = (a2 == c) ? lk : 0.0;
@@ -364,6 +364,10 @@ void dense_launch_step(const DenseView& v, const StepArg* args, const IwpConst* 
   const size_t shm_begin = (size_t(v.k) * v.d + v.d + 4 + size_t(v.n) * v.n) * sizeof(double);
   hipLaunchKernelGGL(dense_begin_kernel, dim3(v.B), dim3(kThreads), shm_begin, s, v, args, K);
   mark(1);
+  if (dense_mfma_supported(v) && !v.force_generic) {
+    dense_launch_mfma_tail(v, args, K, s, ev);
+    return;
+  }
   const int rows_per = v.D < 64 ? v.D : 64;
   hipLaunchKernelGGL(dense_lq_input_kernel, dim3(rows_per, v.B), dim3(kThreads), 0, s, v, args, K);
   mark(2);

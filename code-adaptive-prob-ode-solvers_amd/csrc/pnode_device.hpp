@@ -34,6 +34,7 @@ void iso_launch_smooth(const IsoView& v, const int32_t* num_filled, double* out,
 struct DenseView {
   int B, d, k, n, D, K;
   int ts1, dynamic, vf_id, P, prm_per_traj;
+  int force_generic;  // 1: never take the MFMA fast path (A/B testing)
   double* mean;   // [3][B][n][d]
   double* U;      // [3][B][D][D]   Sigma = U^T U (row-major)
   double* sigma;  // [3][B]
@@ -61,6 +62,9 @@ struct PhaseEvents {
 };
 void dense_launch_step(const DenseView& v, const StepArg* args, const IwpConst* K, hipStream_t s,
                        const PhaseEvents* ev = nullptr);
+bool dense_mfma_supported(const DenseView& v);
+void dense_launch_mfma_tail(const DenseView& v, const StepArg* args, const IwpConst* K, hipStream_t s,
+                            const PhaseEvents* ev);
 void dense_launch_interp(const DenseView& v, const InterpArg* args, const IwpConst* K, hipStream_t s);
 
 }  // namespace pnode

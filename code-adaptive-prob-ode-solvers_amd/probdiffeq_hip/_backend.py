@@ -24,7 +24,7 @@ SYMBOLS = (
     "pnode_set_tolerances pnode_attempt_step pnode_commit pnode_interpolate pnode_checkpoint_at_step "
     "pnode_solve_fixed_grid pnode_read_mean pnode_read_time pnode_read_output_scale pnode_read_factor "
     "pnode_read_checkpoint_means pnode_smooth_checkpoint_means pnode_last_step_ms pnode_set_phase_timing "
-    "pnode_last_phase_ms pnode_stream"
+    "pnode_last_phase_ms pnode_set_generic_path pnode_stream"
 ).split()
 
 
@@ -89,6 +89,7 @@ def load_library():
     lib.pnode_smooth_checkpoint_means.argtypes = [vp, i32p, dp]
     lib.pnode_last_step_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.pnode_set_phase_timing.argtypes = [vp, C.c_int32]
+    lib.pnode_set_generic_path.argtypes = [vp, C.c_int32]
     lib.pnode_last_phase_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.pnode_stream.argtypes = [vp]
     lib.pnode_stream.restype = vp
@@ -238,6 +239,9 @@ class Batch:
         out = np.zeros((self.B, self.K + 1, self.n, self.d))
         _check(self._lib.pnode_smooth_checkpoint_means(self._h, nf.ctypes.data_as(C.POINTER(C.c_int32)), _dp(out)))
         return out
+
+    def set_generic_path(self, enabled=True):
+        _check(self._lib.pnode_set_generic_path(self._h, int(enabled)))
 
     def set_phase_timing(self, enabled=True):
         _check(self._lib.pnode_set_phase_timing(self._h, int(enabled)))

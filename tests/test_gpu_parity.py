@@ -209,6 +209,51 @@ def test_dense_steps_match_oracle(hip_lib, case):
     batch.close()
 
 
+@pytest.mark.parametrize("N,nu", [(16, 3), (32, 3), (16, 5), (32, 4)])
+def test_dense_mfma_path_matches_oracle_and_generic(hip_lib, N, nu):
+    """The MFMA-tiled LQ / measurement-update kernels (d % 16 == 0) against the oracle and against the
+    generic HIP kernels, over several consecutive steps with growing covariance."""
+    vf = V.brusselator(N)
+    B = 3
+    y0 = np.stack([brusselator_y0(N, ph) for ph in (0.0, 0.4, 1.1)])
+    tc = tcoeffs(vf, [y0], nu)
+    tc_arr = np.stack(tc, axis=1)
+    fast = _dense_batch(vf, nu, "ts1", B)
+    slow = _dense_batch(vf, nu, "ts1", B)
+    slow.set_generic_path(True)
+    for bt in (fast, slow):
+        bt.set_initial(tc_arr, np.zeros(B), np.ones(B))
+        bt.set_tolerances(1e-5, 1e-5)
+    cfg = po.SolverConfig(nu=nu, model="dense", correction="ts1", strategy="filter", calibration="dynamic")
+    acfg = po.AdaptiveConfig(1e-5, 1e-5)
+    prob = oracle_problem(vf)
+    states = [po.initial_state(cfg, [c[b] for c in tc], 0.0) for b in range(B)]
+    ef, es = np.zeros(B), np.zeros(B)
+    for it, dt0 in enumerate([0.01, 0.02, 0.015, 0.03]):
+        dts = dt0 * (1.0 + 0.2 * np.arange(B))
+        fast.attempt_step(dts, np.ones(B, np.uint8), ef)
+        slow.attempt_step(dts, np.ones(B, np.uint8), es)
+        fast.commit(np.ones(B, np.uint8))
+        slow.commit(np.ones(B, np.uint8))
+        mf, ms = fast.read_mean(0), slow.read_mean(0)
+        Rf, Rs = fast.read_factor(0), slow.read_factor(0)
+        for b in range(B):
+            e, new = po.step(cfg, prob, states[b], float(dts[b]))
+            en = po.normalise_error(acfg, e, new.mean[0], states[b].mean[0])
+            assert abs(ef[b] - en) <= 1e-7 * en, (it, b, ef[b], en)
+            assert abs(ef[b] - es[b]) <= 1e-7 * en
+            for i in range(nu + 1):
+                tol_i = 1e-11 if i == 0 else (1e-9 if i == 1 else 1e-6)
+                assert relmax(mf[b, i], new.mean[i]) < tol_i, (it, b, i)
+                assert relmax(mf[b, i], ms[b, i]) < tol_i, (it, b, i)
+            cov_ref = new.chol @ new.chol.T
+            assert relmax(Rf[b].T @ Rf[b], cov_ref) < 1e-7, (it, b)
+            assert relmax(Rs[b].T @ Rs[b], cov_ref) < 1e-7, (it, b)
+            states[b] = new
+    fast.close()
+    slow.close()
+
+
 def test_vdp_golden_prefix_through_api(hip_lib, golden):
     """Reference experiment 1 (vdp.py:52-80): stiff Van der Pol, dense EKF1 nu=4, tol 1e-3. The first
     25 accepted grid points agree with the committed JAX grid to rounding (see test_oracle_golden for
