@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -242,6 +243,7 @@ int pnode_create(const pnode_config* cfg, pnode_batch** out) {
     DenseView& v = h->dn;
     v.B = int(B); v.d = d; v.k = k; v.n = int(n); v.D = int(D); v.K = int(Kc);
     v.ts1 = cfg->correction == PNODE_CORR_TS1;
+    v.ablate = getenv("PNODE_ABLATE") ? atoi(getenv("PNODE_ABLATE")) : 0;
     v.dynamic = cfg->calibration == PNODE_CALIB_DYNAMIC;
     v.vf_id = cfg->vf_id; v.P = cfg->num_vf_params; v.prm_per_traj = cfg->vf_params_per_trajectory;
     ALLOC(v.mean, 3 * B * n * d);

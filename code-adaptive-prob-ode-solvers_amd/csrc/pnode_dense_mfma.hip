@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void dense_lq_mfma_kernel(DenseView v, const S
     Tpp[tid] = ((tid >> 4) == (tid & 15)) ? t0diag : 0.0;
     __syncthreads();
     // ---- unblocked row-Householder on the panel
-    for (int c = 0; c < kNB; ++c) {
+    for (int c = 0; c < ((v.ablate & 1) ? 0 : kNB); ++c) {
       if (rr == c) {
         double part = 0.0;
 #pragma unroll
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void dense_lq_mfma_kernel(DenseView v, const S
       for (int q = 0; q < 4; ++q) Gs[wv * 256 + (g + 4 * q) * kNB + r] = acc[q];
     }
     __syncthreads();
-    if (tid < kNB) {
+    if (tid < kNB && !(v.ablate & 4)) {
       // lane i owns row i of Tf (upper triangular, forward product H_0 H_1 ... = I - V^T Tf V)
       const int i = tid;
       double row[kNB];
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void dense_lq_mfma_kernel(DenseView v, const S
     }
     __syncthreads();
     // ---- trailing update, one 16-row strip per wave at a time
-    const int nstrips = DT - 1 - p;
+    const int nstrips = (v.ablate & 2) ? 0 : DT - 1 - p;
     for (int st = wv; st < nstrips; st += 4) {
       const int j0 = c0 + kNB * (st + 1);
       double* __restrict__ rowp = Mt + size_t(j0 + r) * D + g;
@@ -202,6 +202,262 @@ __global__ __launch_bounds__(256) void dense_lq_mfma_kernel(DenseView v, const S
       }
 #pragma unroll
       for (int s = 0; s < NS; ++s) rowp[4 * s] = X[s];
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Blocked LQ, second generation: 32-row outer blocks (two 16-row panels A, B per pass over the
+// trailing rows, halving the trailing-matrix traffic), DPP reductions and ONE barrier per panel row.
+// Strip register layout for HBM rows (128 contiguous bytes per lane per 64-column super-tile):
+//      X[16 T + 4 j + q] = M[row0 + r][64 T + 16 g + 4 j + q]
+// ---------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// Sum over the 16 lanes of a DPP row; every lane of the row receives the total.
+__device__ __forceinline__ double row16_sum(double v) {
+  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);  // row_half_mirror
+  v += dpp_mov<0x140>(v);  // row_mirror
+  return v;
+}
+
+struct PanelScratch {
+  double* Tpp;    // [16][16] diagonal block of T (lower)
+  double* Tf;     // [16][16] compact-WY factor
+  double* tau;    // [16]
+  double* scl;    // [16]
+  double* beta;   // [16]
+};
+
+// Row-Householder factorisation of the 16 LDS rows starting at `rows` (stride LDV); one barrier per
+// row. Groups above the pivot row (idle in a textbook sweep) compute the Gram entries the T-factor
+// needs. On exit the rows hold the reflector vectors, ps.Tpp the final diagonal block, ps.Tf the
+// T-factor.
+template <int DT, int LDV>
+__device__ __forceinline__ void factor_panel(double* rows, const PanelScratch& ps, double* Gm, double t0diag, int tid) {
+  constexpr int D = 16 * DT;
+  const int rr = tid >> 4, ch = tid & 15;
+  ps.Tpp[tid] = (rr == ch) ? t0diag : 0.0;
+  __syncthreads();
+  for (int c = 0; c < kNB; ++c) {
+    double xc[DT];
+    double part = 0.0;
+#pragma unroll
+    for (int i = 0; i < DT; ++i) {
+      xc[i] = rows[c * LDV + ch + 16 * i];
+      part += xc[i] * xc[i];
+    }
+    const double xx = row16_sum(part);
+    const double alpha = ps.Tpp[c * kNB + c];
+    double tauc = 0.0, scale = 0.0, beta = alpha;
+    if (xx != 0.0) {
+      beta = -copysign(sqrt(alpha * alpha + xx), alpha);
+      tauc = (beta - alpha) / beta;
+      scale = 1.0 / (alpha - beta);
+    }
+    if (rr != c) {
+      double dpart = 0.0;
+#pragma unroll
+      for (int i = 0; i < DT; ++i) dpart += rows[rr * LDV + ch + 16 * i] * xc[i];
+      const double dot = row16_sum(dpart);
+      if (rr > c) {
+        if (tauc != 0.0) {
+          const double tjc = ps.Tpp[rr * kNB + c];
+          const double w = tauc * (tjc + scale * dot);
+          const double ws = w * scale;
+#pragma unroll
+          for (int i = 0; i < DT; ++i) rows[rr * LDV + ch + 16 * i] -= ws * xc[i];
+          if (ch == 0) ps.Tpp[rr * kNB + c] = tjc - w;
+        }
+      } else if (ch == 0) {
+        Gm[rr * kNB + c] = ps.scl[rr] * scale * dot;  // vx_rr . vx_c  (rr < c: row rr is final)
+      }
+    } else if (ch == 0) {
+      ps.beta[c] = beta;
+      ps.tau[c] = tauc;
+      ps.scl[c] = scale;
+    }
+    __syncthreads();
+  }
+  // scale the rows into reflector vectors, finalise the diagonal of T, build the T-factor
+  for (int idx = tid; idx < kNB * D; idx += 256) {
+    const int i = idx / D, cidx = idx % D;
+    rows[i * LDV + cidx] *= ps.scl[i];
+  }
+  if (tid < kNB) {
+    ps.Tpp[tid * kNB + tid] = ps.beta[tid];
+    const int i = tid;
+    double row[kNB];
+#pragma unroll
+    for (int j = 0; j < kNB; ++j) {
+      const double tj = ps.tau[j];
+      double acc = 0.0;
+#pragma unroll
+      for (int m = 0; m < kNB; ++m)
+        if (m < j) acc += row[m] * Gm[m * kNB + j];
+      row[j] = (i == j) ? tj : ((i < j) ? -tj * acc : 0.0);
+    }
+#pragma unroll
+    for (int j = 0; j < kNB; ++j) ps.Tf[i * kNB + j] = row[j];
+  }
+  __syncthreads();
+}
+
+// One panel's reflectors applied to a register strip X (HBM layout). Writes T[J][P] = T0 - W.
+template <int DT, int LDV>
+__device__ __forceinline__ void apply_panel_to_strip(double (&X)[4 * DT], const double* __restrict__ Vp,
+                                                     const double* __restrict__ Tfp, double4_t t0v,
+                                                     double* __restrict__ Tout, int r, int g) {
+  double4_t a0 = t0v, a1 = {0.0, 0.0, 0.0, 0.0}, a2 = a1, a3 = a1;
+#pragma unroll
+  for (int T = 0; T < DT / 4; ++T) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double* vrow = Vp + r * LDV + 64 * T + 16 * g + q;
+      a0 = MFMA64(vrow[0], X[16 * T + q], a0);
+      a1 = MFMA64(vrow[4], X[16 * T + 4 + q], a1);
+      a2 = MFMA64(vrow[8], X[16 * T + 8 + q], a2);
+      a3 = MFMA64(vrow[12], X[16 * T + 12 + q], a3);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keep the LDS operand loads of later super-tiles from being hoisted
+  }
+  const double4_t acc = (a0 + a1) + (a2 + a3);
+  double4_t w4 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) w4 = MFMA64(Tfp[(4 * kk + g) * kNB + r], acc[kk], w4);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) Tout[g + 4 * q] = t0v[q] - w4[q];
+  const int coff = 16 * (r & 3) + (r >> 2);
+#pragma unroll
+  for (int T = 0; T < DT / 4; ++T) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      double4_t c4 = {X[16 * T + 4 * j], X[16 * T + 4 * j + 1], X[16 * T + 4 * j + 2], X[16 * T + 4 * j + 3]};
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) c4 = MFMA64(-Vp[(4 * kk + g) * LDV + 64 * T + 4 * j + coff], w4[kk], c4);
+      X[16 * T + 4 * j] = c4[0];
+      X[16 * T + 4 * j + 1] = c4[1];
+      X[16 * T + 4 * j + 2] = c4[2];
+      X[16 * T + 4 * j + 3] = c4[3];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, const StepArg* __restrict__ args,
+                                                             const IwpConst* __restrict__ Kc) {
+  static_assert(DT % 4 == 0, "the HBM strip layout needs D % 64 == 0");
+  constexpr int D = 16 * DT;
+  constexpr int LDV = D + 1;  // 2*LDV = 2 (mod 64) dwords: conflict-free A-operand reads in the G phase
+  __shared__ double Vx[2 * kNB * LDV];
+  __shared__ double TppS[2 * kNB * kNB];
+  __shared__ double TfS[2 * kNB * kNB];
+  __shared__ double Gm[kNB * kNB];
+  __shared__ double small[6 * kNB];
+
+  const int b = blockIdx.x;
+  if (!args[b].active) return;
+  const IwpConst& K = *Kc;
+  const int d = v.d;
+  const double sigma = v.sig_new[b];
+  double* __restrict__ Mt = v.M + size_t(b) * D * D;
+  double* __restrict__ T = v.R + size_t(b) * D * D;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  PanelScratch psA{TppS, TfS, small, small + 16, small + 32};
+  PanelScratch psB{TppS + 256, TfS + 256, small + 48, small + 64, small + 80};
+  double* VA = Vx;
+  double* VB = Vx + kNB * LDV;
+
+  auto t0_tile = [&](int row0, int col0) {
+    // T0[row0 + r][col0 + g + 4q]: sigma * chol(Qbar)[iblk_row][iblk_col] where the intra-block indices agree
+    double4_t t;
+    const int ib = row0 / d, jb = col0 / d;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      t[q] = (((row0 + r) % d) == ((col0 + g + 4 * q) % d) && jb <= ib) ? sigma * K.qsT[jb][ib] : 0.0;
+    return t;
+  };
+
+  for (int P = 0; P < DT / 2; ++P) {
+    const int c0 = 2 * kNB * P;
+    for (int idx = tid; idx < 2 * kNB * D; idx += 256) {
+      const int i = idx / D, c = idx % D;
+      Vx[i * LDV + c] = Mt[size_t(c0 + i) * D + c];
+    }
+    __syncthreads();
+    // ---- panel A
+    factor_panel<DT, LDV>(VA, psA, Gm, sigma * K.qsT[c0 / d][c0 / d], tid);
+    // ---- panel B rows <- reflectors of A (rows live in LDS; natural column order 16 tt + m)
+    {
+      double4_t acc = t0_tile(c0 + kNB, c0);
+      const double4_t t0v = acc;
+#pragma unroll 8
+      for (int s = 0; s < D / 4; ++s) acc = MFMA64(VA[r * LDV + 4 * s + g], VB[r * LDV + 4 * s + g], acc);
+      double4_t w4 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) w4 = MFMA64(psA.Tf[(4 * kk + g) * kNB + r], acc[kk], w4);
+      if (wv == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) T[size_t(c0 + kNB + r) * D + c0 + g + 4 * q] = t0v[q] - w4[q];
+      }
+      __syncthreads();  // every wave has read all of B before anyone overwrites its tiles
+      for (int tt = wv; tt < DT; tt += 4) {
+        double4_t c4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) c4[q] = VB[r * LDV + 16 * tt + g + 4 * q];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) c4 = MFMA64(-VA[(4 * kk + g) * LDV + 16 * tt + r], w4[kk], c4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) VB[r * LDV + 16 * tt + g + 4 * q] = c4[q];
+      }
+      __syncthreads();
+    }
+    // ---- panel B
+    factor_panel<DT, LDV>(VB, psB, Gm, sigma * K.qsT[(c0 + kNB) / d][(c0 + kNB) / d], tid);
+    // ---- diagonal blocks of T
+    {
+      const int i = tid >> 4, j = tid & 15;
+      if (j <= i) {
+        T[size_t(c0 + i) * D + c0 + j] = psA.Tpp[i * kNB + j];
+        T[size_t(c0 + kNB + i) * D + c0 + kNB + j] = psB.Tpp[i * kNB + j];
+      }
+    }
+    // ---- trailing strips: both panels in one pass over the rows
+    const int nstrips = DT - 2 * (P + 1);
+    for (int st = wv; st < nstrips; st += 4) {
+      const int j0 = c0 + 2 * kNB + kNB * st;
+      double* __restrict__ rowp = Mt + size_t(j0 + r) * D + 16 * g;
+      double X[4 * DT];
+#pragma unroll
+      for (int T4 = 0; T4 < DT / 4; ++T4)
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+          const double2 t2 = *reinterpret_cast<const double2*>(rowp + 64 * T4 + e);
+          X[16 * T4 + e] = t2.x;
+          X[16 * T4 + e + 1] = t2.y;
+        }
+      double* Trow = T + size_t(j0 + r) * D + c0;
+      apply_panel_to_strip<DT, LDV>(X, VA, psA.Tf, t0_tile(j0, c0), Trow, r, g);
+      apply_panel_to_strip<DT, LDV>(X, VB, psB.Tf, t0_tile(j0, c0 + kNB), Trow + kNB, r, g);
+#pragma unroll
+      for (int T4 = 0; T4 < DT / 4; ++T4)
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+          double2 t2;
+          t2.x = X[16 * T4 + e];
+          t2.y = X[16 * T4 + e + 1];
+          *reinterpret_cast<double2*>(rowp + 64 * T4 + e) = t2;
+        }
     }
     __syncthreads();
   }
@@ -395,7 +651,10 @@ static void launch_mfma(const DenseView& v, const StepArg* args, const IwpConst*
   };
   hipLaunchKernelGGL(dense_mt_kernel, dim3(64, v.B), dim3(256), 0, s, v, args, K);
   mark(2);
-  hipLaunchKernelGGL((dense_lq_mfma_kernel<DT>), dim3(v.B), dim3(256), 0, s, v, args, K);
+  if (v.ablate & 8)
+    hipLaunchKernelGGL((dense_lq_mfma_kernel<DT>), dim3(v.B), dim3(256), 0, s, v, args, K);
+  else
+    hipLaunchKernelGGL((dense_lq2_mfma_kernel<DT>), dim3(v.B), dim3(256), 0, s, v, args, K);
   mark(3);
   constexpr int d = 16 * DD, W2 = 2 * d;
   const size_t shm = (size_t(d) * (W2 + 2) + size_t(d) * (d + 1) + d + W2 + 4 + kMaxN) * sizeof(double);
