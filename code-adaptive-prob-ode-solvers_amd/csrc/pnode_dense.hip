@@ -361,10 +361,14 @@ void dense_launch_step(const DenseView& v, const StepArg* args, const IwpConst* 
     if (ev) (void)hipEventRecord(ev->ev[i], s);
   };
   mark(0);
+  const bool fast = dense_mfma_supported(v) && !v.force_generic;
   const size_t shm_begin = (size_t(v.k) * v.d + v.d + 4 + size_t(v.n) * v.n) * sizeof(double);
-  hipLaunchKernelGGL(dense_begin_kernel, dim3(v.B), dim3(kThreads), shm_begin, s, v, args, K);
+  if (fast && v.ts1 && !(v.ablate & 32))
+    dense_launch_mfma_begin(v, args, K, s);
+  else
+    hipLaunchKernelGGL(dense_begin_kernel, dim3(v.B), dim3(kThreads), shm_begin, s, v, args, K);
   mark(1);
-  if (dense_mfma_supported(v) && !v.force_generic) {
+  if (fast) {
     dense_launch_mfma_tail(v, args, K, s, ev);
     return;
   }

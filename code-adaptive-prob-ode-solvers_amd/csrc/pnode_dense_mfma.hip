@@ -616,6 +616,298 @@ __global__ __launch_bounds__(256) void dense_correct_mfma_kernel(DenseView v, co
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Second-generation begin / measurement-update kernels: small LDS footprints (several workgroups per
+// CU hide the latency of the sequential d x d Cholesky), F/W kept in global memory (L2), and the
+// D x 2d strip update spread over B * DT/4 workgroups.
+// ---------------------------------------------------------------------------------------------
+
+// Workgroup-cooperative lower Cholesky of a d x d matrix in LDS (leading dimension LD).
+template <int d, int LD>
+__device__ __forceinline__ void lds_cholesky(double* Sm, int tid) {
+  for (int c = 0; c < d; ++c) {
+    const double piv = sqrt(Sm[c * LD + c]);
+    __syncthreads();
+    if (tid == 0) Sm[c * LD + c] = piv;
+    for (int rr = c + 1 + tid; rr < d; rr += 256) Sm[rr * LD + c] /= piv;
+    __syncthreads();
+    const int m = d - c - 1;
+    for (int idx = tid; idx < m * m; idx += 256) {
+      const int rr = c + 1 + idx / m, q = c + 1 + idx % m;
+      if (q <= rr) Sm[rr * LD + q] -= Sm[rr * LD + c] * Sm[q * LD + c];
+    }
+    __syncthreads();
+  }
+}
+
+template <int DD>
+__global__ __launch_bounds__(256) void dense_begin_mfma_kernel(DenseView v, const StepArg* __restrict__ args,
+                                                               const IwpConst* __restrict__ Kc) {
+  constexpr int d = 16 * DD, LD = d + 1;
+  __shared__ double Sm[d * LD];
+  __shared__ double ybuf[d];
+  __shared__ double zbuf[d];
+  __shared__ double red[4];
+  const int b = blockIdx.x;
+  const StepArg arg = args[b];
+  if (!arg.active) return;
+  const IwpConst& K = *Kc;
+  const int n = v.n;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  double p[kMaxN], pinv[kMaxN];
+  precond_rt(n, arg.dt, K, p, pinv);
+  const double lq00 = p[0] * K.qsT[0][0], lq10 = p[1] * K.qsT[0][1], lq11 = p[1] * K.qsT[1][1];
+  const size_t sB = size_t(v.B);
+  const double* msrc = v.mean + (size_t(arg.src) * sB + b) * n * d;
+  double* mdst = v.mean + (size_t(arg.dst) * sB + b) * n * d;
+  for (int j = tid; j < d; j += 256) {
+    for (int i = 0; i < n; ++i) {
+      double acc = 0.0;
+      for (int kk = i; kk < n; ++kk) acc += K.a[i][kk] * pinv[kk] * msrc[kk * d + j];
+      const double e = p[i] * acc;
+      mdst[i * d + j] = e;
+      if (i == 0) ybuf[j] = e;
+    }
+  }
+  __syncthreads();
+  VfCtx ctx{v.vf_id, d, 1, v.prm ? v.prm + (v.prm_per_traj ? size_t(b) * v.P : 0) : nullptr};
+  const double tnew = arg.t + arg.dt;
+  double* zg = v.z + size_t(b) * d;
+  for (int j = tid; j < d; j += 256) {
+    const double z = mdst[d + j] - vf_f(ctx, ybuf, j, tnew);
+    zbuf[j] = z;
+    zg[j] = z;
+  }
+  // B0 = lq10 I - lq00 J, kept in LDS (Sm doubles as its buffer until the Gram is formed in registers)
+  double* Jg = v.J + size_t(b) * d * d;
+  for (int idx = tid; idx < d * d; idx += 256) {
+    const int a = idx / d, q = idx % d;
+    const double jv = vf_jac(ctx, ybuf, a, 0, q, tnew);
+    Jg[idx] = jv;
+    Sm[a * LD + q] = ((a == q) ? lq10 : 0.0) - lq00 * jv;
+  }
+  __syncthreads();
+  // S1 = B0 B0^T + lq11^2 I  (lower tiles), accumulated in registers, then written over B0
+  constexpr int NT = DD * (DD + 1) / 2;
+  double4_t accs[(NT + 3) / 4];
+  int cnt = 0;
+  for (int tile = wv; tile < NT; tile += 4, ++cnt) {
+    int ta = 0, rem = tile;
+    while (rem > ta) { rem -= ta + 1; ++ta; }
+    const int tb = rem;
+    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int s = 0; s < d / 4; ++s)
+      acc = MFMA64(Sm[(16 * ta + r) * LD + 4 * s + g], Sm[(16 * tb + r) * LD + 4 * s + g], acc);
+    accs[cnt] = acc;
+  }
+  __syncthreads();
+  cnt = 0;
+  double* errg = v.err + size_t(b) * d;
+  for (int tile = wv; tile < NT; tile += 4, ++cnt) {
+    int ta = 0, rem = tile;
+    while (rem > ta) { rem -= ta + 1; ++ta; }
+    const int tb = rem;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = 16 * ta + g + 4 * q, col = 16 * tb + r;
+      const double val = accs[cnt][q] + ((row == col) ? lq11 * lq11 : 0.0);
+      Sm[row * LD + col] = val;
+      if (row == col) errg[row] = val;
+    }
+  }
+  __syncthreads();
+  lds_cholesky<d, LD>(Sm, tid);
+  for (int a = 0; a < d; ++a) {  // w = C^-1 z
+    const double xa = zbuf[a] / Sm[a * LD + a];
+    __syncthreads();
+    if (tid == 0) zbuf[a] = xa;
+    for (int rr = a + 1 + tid; rr < d; rr += 256) zbuf[rr] -= Sm[rr * LD + a] * xa;
+    __syncthreads();
+  }
+  double part = 0.0;
+  for (int j = tid; j < d; j += 256) part += zbuf[j] * zbuf[j];
+  part = wave_sum(part);
+  if (lane == 0) red[wv] = part;
+  __syncthreads();
+  const double sigma_hat = sqrt((red[0] + red[1] + red[2] + red[3]) / double(d));
+  for (int j = tid; j < d; j += 256) errg[j] = arg.dt * sigma_hat * sqrt(errg[j]);
+  if (tid == 0) v.sig_new[b] = v.dynamic ? sigma_hat : v.sigma[size_t(arg.src) * sB + b];
+}
+
+// Gain kernel: F = H L^-, S = F F^T = C C^T, W = C^-1 F (to global v.Ft), tv = W^T C^-1 z (to v.X).
+template <int DT, int DD>
+__global__ __launch_bounds__(256, 2) void dense_gain_mfma_kernel(DenseView v, const StepArg* __restrict__ args,
+                                                              const IwpConst* __restrict__ Kc) {
+  constexpr int D = 16 * DT, d = 16 * DD, W2 = 2 * d, LD = d + 1;
+  __shared__ double Sm[d * LD];
+  __shared__ double wz[d];
+  const int b = blockIdx.x;
+  const StepArg arg = args[b];
+  if (!arg.active) return;
+  const IwpConst& K = *Kc;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  double p[kMaxN], pinv[kMaxN];
+  precond_rt(v.n, arg.dt, K, p, pinv);
+  const double p0 = p[0], p1 = p[1];
+  const double* __restrict__ T = v.R + size_t(b) * D * D;
+  const double* __restrict__ Jg = v.J + size_t(b) * d * d;
+  double* __restrict__ F = v.Ft + size_t(b) * d * D;  // [d][W2] used
+  for (int idx = tid; idx < d * W2; idx += 256) {
+    const int a = idx / W2, c = idx % W2;
+    double acc = (c <= d + a) ? p1 * T[size_t(d + a) * D + c] : 0.0;
+    if (c < d) {
+      double s = 0.0;
+      for (int q = c; q < d; ++q) s += Jg[a * d + q] * T[size_t(q) * D + c];
+      acc -= p0 * s;
+    }
+    F[idx] = acc;
+  }
+  for (int j = tid; j < d; j += 256) wz[j] = v.z[size_t(b) * d + j];
+  __syncthreads();
+  for (int tile = wv; tile < DD * DD; tile += 4) {
+    const int ta = tile / DD, tb = tile % DD;
+    if (tb > ta) continue;
+    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 8
+    for (int s = 0; s < W2 / 4; ++s)
+      acc = MFMA64(F[(16 * ta + r) * W2 + 4 * s + g], F[(16 * tb + r) * W2 + 4 * s + g], acc);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) Sm[(16 * ta + g + 4 * q) * LD + 16 * tb + r] = acc[q];
+  }
+  __syncthreads();
+  lds_cholesky<d, LD>(Sm, tid);
+  // one thread per column of F (and one for z): register-resident forward substitution
+  if (tid <= W2) {
+    double col[d];
+    if (tid < W2) {
+#pragma unroll
+      for (int a = 0; a < d; ++a) col[a] = F[a * W2 + tid];
+    } else {
+#pragma unroll
+      for (int a = 0; a < d; ++a) col[a] = wz[a];
+    }
+#pragma unroll
+    for (int a = 0; a < d; ++a) {
+      const double w = col[a] / Sm[a * LD + a];
+      col[a] = w;
+#pragma unroll
+      for (int a2 = a + 1; a2 < d; ++a2) col[a2] -= Sm[a2 * LD + a] * w;
+    }
+    if (tid < W2) {
+#pragma unroll
+      for (int a = 0; a < d; ++a) F[a * W2 + tid] = col[a];
+    }
+    if (tid == W2) {
+#pragma unroll
+      for (int a = 0; a < d; ++a) wz[a] = col[a];
+    }
+  }
+  __syncthreads();  // W (global, this workgroup) and the solved wz are visible
+  if (tid < W2) {
+    double acc = 0.0;
+    for (int a = 0; a < d; ++a) acc += F[a * W2 + tid] * wz[a];
+    v.X[size_t(b) * D * d + tid] = acc;  // tv lives at the head of the X scratch
+  }
+}
+
+// Strip update: Y^T = W X^T, X^T -= W^T Y^T on the first 2d columns, copy of the rest, mean update,
+// and (block 0: rows of the zeroth derivative) the normalised error norm.
+template <int DT, int DD>
+__global__ __launch_bounds__(256, 2) void dense_strip_update_mfma_kernel(DenseView v, const StepArg* __restrict__ args,
+                                                                         const IwpConst* __restrict__ Kc) {
+  constexpr int D = 16 * DT, d = 16 * DD, W2 = 2 * d, LDF = W2 + 1;
+  extern __shared__ double smem[];
+  double* Fw = smem;          // [d][LDF]
+  double* tv = Fw + d * LDF;  // [W2]
+  double* red = tv + W2;      // [4]
+  const int b = blockIdx.y;
+  const StepArg arg = args[b];
+  if (!arg.active) return;
+  const IwpConst& K = *Kc;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const double* __restrict__ T = v.R + size_t(b) * D * D;
+  const double* __restrict__ Wg = v.Ft + size_t(b) * d * D;
+  for (int idx = tid; idx < d * W2; idx += 256) Fw[(idx / W2) * LDF + idx % W2] = Wg[idx];
+  for (int c = tid; c < W2; c += 256) tv[c] = v.X[size_t(b) * D * d + c];
+  __syncthreads();
+  const size_t sB = size_t(v.B);
+  double* mdst = v.mean + (size_t(arg.dst) * sB + b) * D;
+  double* __restrict__ Ln = v.U + (size_t(arg.dst) * sB + b) * D * D;
+  const int st = 4 * blockIdx.x + wv;
+  if (st < DT) {
+    const int row = 16 * st + r;
+    const int iblk = (16 * st) / d;
+    double pr;
+    {
+      double p[kMaxN], pinv[kMaxN];
+      precond_rt(v.n, arg.dt, K, p, pinv);
+      pr = p[0];
+#pragma unroll
+      for (int i = 1; i < kMaxN; ++i) pr = (i == iblk) ? p[i] : pr;
+    }
+    double X[W2 / 4];
+    double mpart = 0.0;
+#pragma unroll
+    for (int s = 0; s < W2 / 4; ++s) {
+      const int c = 4 * s + g;
+      X[s] = (c <= row) ? pr * T[size_t(row) * D + c] : 0.0;
+      mpart += X[s] * tv[c];
+    }
+    mpart += __shfl_xor(mpart, 16, kWave);
+    mpart += __shfl_xor(mpart, 32, kWave);
+    if (g == 0) mdst[row] -= mpart;
+    double4_t yT[DD];
+#pragma unroll
+    for (int ta = 0; ta < DD; ++ta) {
+      double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < W2 / 4; ++s) acc = MFMA64(Fw[(16 * ta + r) * LDF + 4 * s + g], X[s], acc);
+      yT[ta] = acc;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int t = 0; t < W2 / 16; ++t) {
+      double4_t c4 = {X[4 * t], X[4 * t + 1], X[4 * t + 2], X[4 * t + 3]};
+#pragma unroll
+      for (int kk = 0; kk < d / 4; ++kk) c4 = MFMA64(-Fw[(4 * kk + g) * LDF + 16 * t + r], yT[kk >> 2][kk & 3], c4);
+      X[4 * t] = c4[0];
+      X[4 * t + 1] = c4[1];
+      X[4 * t + 2] = c4[2];
+      X[4 * t + 3] = c4[3];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int s = 0; s < W2 / 4; ++s) Ln[size_t(row) * D + 4 * s + g] = X[s];
+    // the remaining columns of these 16 rows are plain (scaled) copies of the triangular factor
+    for (int rr = 0; rr < 16; ++rr) {
+      const int row2 = 16 * st + rr;
+      for (int c = W2 + lane; c < D; c += kWave)
+        Ln[size_t(row2) * D + c] = (c <= row2) ? pr * T[size_t(row2) * D + c] : 0.0;
+    }
+  }
+  if (blockIdx.x == 0) {
+    // rows 0 .. 63 of the state are covered by this block when d <= 64: error norm over u = m[0]
+    __syncthreads();
+    const double atol = v.atol[b], rtol = v.rtol[b];
+    double part = 0.0;
+    for (int j = tid; j < d; j += 256) {
+      const double rel = v.err[size_t(b) * d + j] / (atol + rtol * fabs(mdst[j]));
+      part += rel * rel;
+    }
+    part = wave_sum(part);
+    if (lane == 0) red[wv] = part;
+    __syncthreads();
+    if (tid == 0) {
+      v.errnorm[b] = sqrt((red[0] + red[1] + red[2] + red[3]) / double(d));
+      v.sigma[size_t(arg.dst) * sB + b] = v.sig_new[b];
+    }
+  }
+}
+
 // Mt = (Abar P^-1 (x) I) L  only (T0 is generated inside the LQ kernel).
 __global__ __launch_bounds__(256) void dense_mt_kernel(DenseView v, const StepArg* __restrict__ args,
                                                        const IwpConst* __restrict__ Kc) {
@@ -657,6 +949,20 @@ static void launch_mfma(const DenseView& v, const StepArg* args, const IwpConst*
     hipLaunchKernelGGL((dense_lq2_mfma_kernel<DT>), dim3(v.B), dim3(256), 0, s, v, args, K);
   mark(3);
   constexpr int d = 16 * DD, W2 = 2 * d;
+  if (!(v.ablate & 16)) {
+    static_assert(DD <= 4, "the error norm is computed by strip block 0, which must cover the d rows of u");
+    hipLaunchKernelGGL((dense_gain_mfma_kernel<DT, DD>), dim3(v.B), dim3(256), 0, s, v, args, K);
+    const size_t shm2 = (size_t(d) * (W2 + 1) + W2 + 4) * sizeof(double);
+    static bool attr2 = false;
+    if (!attr2) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_strip_update_mfma_kernel<DT, DD>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, int(shm2));
+      attr2 = true;
+    }
+    hipLaunchKernelGGL((dense_strip_update_mfma_kernel<DT, DD>), dim3((DT + 3) / 4, v.B), dim3(256), shm2, s, v, args, K);
+    mark(4);
+    return;
+  }
   const size_t shm = (size_t(d) * (W2 + 2) + size_t(d) * (d + 1) + d + W2 + 4 + kMaxN) * sizeof(double);
   static bool attr_set = false;
   if (!attr_set) {
@@ -669,6 +975,12 @@ static void launch_mfma(const DenseView& v, const StepArg* args, const IwpConst*
 }
 
 // Launches lq-input + LQ + correct (the caller has already launched the begin kernel and marked 0, 1).
+void dense_launch_mfma_begin(const DenseView& v, const StepArg* args, const IwpConst* K, hipStream_t s) {
+  const int DD = v.d / 16;
+  if (DD == 2) hipLaunchKernelGGL((dense_begin_mfma_kernel<2>), dim3(v.B), dim3(256), 0, s, v, args, K);
+  else hipLaunchKernelGGL((dense_begin_mfma_kernel<4>), dim3(v.B), dim3(256), 0, s, v, args, K);
+}
+
 void dense_launch_mfma_tail(const DenseView& v, const StepArg* args, const IwpConst* K, hipStream_t s,
                             const PhaseEvents* ev) {
   const int DT = v.D / 16, DD = v.d / 16;

@@ -64,6 +64,7 @@ struct PhaseEvents {
 void dense_launch_step(const DenseView& v, const StepArg* args, const IwpConst* K, hipStream_t s,
                        const PhaseEvents* ev = nullptr);
 bool dense_mfma_supported(const DenseView& v);
+void dense_launch_mfma_begin(const DenseView& v, const StepArg* args, const IwpConst* K, hipStream_t s);
 void dense_launch_mfma_tail(const DenseView& v, const StepArg* args, const IwpConst* K, hipStream_t s,
                             const PhaseEvents* ev);
 void dense_launch_interp(const DenseView& v, const InterpArg* args, const IwpConst* K, hipStream_t s);
