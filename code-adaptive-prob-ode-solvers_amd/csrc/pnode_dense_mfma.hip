@@ -622,22 +622,93 @@ __global__ __launch_bounds__(256) void dense_correct_mfma_kernel(DenseView v, co
 // D x 2d strip update spread over B * DT/4 workgroups.
 // ---------------------------------------------------------------------------------------------
 
-// Workgroup-cooperative lower Cholesky of a d x d matrix in LDS (leading dimension LD).
-template <int d, int LD>
-__device__ __forceinline__ void lds_cholesky(double* Sm, int tid) {
-  for (int c = 0; c < d; ++c) {
-    const double piv = sqrt(Sm[c * LD + c]);
+// Blocked lower Cholesky of a d x d matrix in LDS (leading dimension LD, d = 16*DD), 256 threads.
+// Per 16-column block: (1) one wave factors the 16 x 16 diagonal block in registers (lane = row,
+// pivots broadcast with v_readlane), (2) the rows below are solved against it (lane = row),
+// (3) the trailing tiles are updated with MFMA. Three barriers per block instead of three per column.
+template <int DD, int LD>
+__device__ __forceinline__ void lds_cholesky_blocked(double* Sm, int tid) {
+  const int lane = tid & 63, wv = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+#pragma unroll 1
+  for (int kb = 0; kb < DD; ++kb) {
+    const int o = 16 * kb;
+    if (wv == 0) {
+      double a[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) a[j] = Sm[(o + r) * LD + o + j];  // lanes 16..63 duplicate rows 0..15
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const double piv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a[c]), c),
+                                            __builtin_amdgcn_readlane(__double2loint(a[c]), c));
+        const double sq = sqrt(piv);
+        a[c] = (r == c) ? sq : a[c] / sq;
+#pragma unroll
+        for (int q = c + 1; q < 16; ++q) {
+          const double lq = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a[c]), q),
+                                             __builtin_amdgcn_readlane(__double2loint(a[c]), q));
+          a[q] -= a[c] * lq;
+        }
+      }
+      if (lane < 16) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+          if (j <= r) Sm[(o + r) * LD + o + j] = a[j];
+      }
+    }
     __syncthreads();
-    if (tid == 0) Sm[c * LD + c] = piv;
-    for (int rr = c + 1 + tid; rr < d; rr += 256) Sm[rr * LD + c] /= piv;
+    // rows below the diagonal block: x L11^T = a_row
+    for (int row = o + 16 + tid; row < 16 * DD; row += 256) {
+      double x[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) x[j] = Sm[row * LD + o + j];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        double acc = x[c];
+#pragma unroll
+        for (int m = 0; m < c; ++m) acc -= x[m] * Sm[(o + c) * LD + o + m];
+        x[c] = acc / Sm[(o + c) * LD + o + c];
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) Sm[row * LD + o + j] = x[j];
+    }
     __syncthreads();
-    const int m = d - c - 1;
-    for (int idx = tid; idx < m * m; idx += 256) {
-      const int rr = c + 1 + idx / m, q = c + 1 + idx % m;
-      if (q <= rr) Sm[rr * LD + q] -= Sm[rr * LD + c] * Sm[q * LD + c];
+    // trailing update A22 -= L21 L21^T (lower tiles)
+    const int nt = DD - kb - 1;
+    for (int tile = wv; tile < nt * (nt + 1) / 2; tile += 4) {
+      int ta = 0, rem = tile;
+      while (rem > ta) { rem -= ta + 1; ++ta; }
+      const int ra = o + 16 * (ta + 1), rb = o + 16 * (rem + 1);
+      double4_t acc;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = Sm[(ra + g + 4 * q) * LD + rb + r];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = MFMA64(-Sm[(ra + r) * LD + o + 4 * s + g], Sm[(rb + r) * LD + o + 4 * s + g], acc);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Sm[(ra + g + 4 * q) * LD + rb + r] = acc[q];
     }
     __syncthreads();
   }
+}
+
+// x <- C^-1 x for lower-triangular C (d x d in LDS), x of length d <= 64 in LDS: one wave, lane = row.
+template <int d, int LD>
+__device__ __forceinline__ void lds_forward_vec_wave(const double* Sm, double* x, int tid) {
+  if (tid < 64) {
+    const int row = tid < d ? tid : d - 1;
+    double xr = x[row];
+    const double inv = 1.0 / Sm[row * LD + row];
+#pragma unroll 8
+    for (int a = 0; a < d; ++a) {
+      const double cand = xr * inv;  // meaningful on lane a
+      const double xa = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(cand), a),
+                                         __builtin_amdgcn_readlane(__double2loint(cand), a));
+      if (row == a) xr = xa;
+      else if (row > a) xr -= Sm[row * LD + a] * xa;
+    }
+    if (tid < d) x[tid] = xr;
+  }
+  __syncthreads();
 }
 
 template <int DD>
@@ -718,14 +789,8 @@ __global__ __launch_bounds__(256) void dense_begin_mfma_kernel(DenseView v, cons
     }
   }
   __syncthreads();
-  lds_cholesky<d, LD>(Sm, tid);
-  for (int a = 0; a < d; ++a) {  // w = C^-1 z
-    const double xa = zbuf[a] / Sm[a * LD + a];
-    __syncthreads();
-    if (tid == 0) zbuf[a] = xa;
-    for (int rr = a + 1 + tid; rr < d; rr += 256) zbuf[rr] -= Sm[rr * LD + a] * xa;
-    __syncthreads();
-  }
+  lds_cholesky_blocked<DD, LD>(Sm, tid);
+  lds_forward_vec_wave<d, LD>(Sm, zbuf, tid);  // w = C^-1 z
   double part = 0.0;
   for (int j = tid; j < d; j += 256) part += zbuf[j] * zbuf[j];
   part = wave_sum(part);
@@ -755,15 +820,24 @@ __global__ __launch_bounds__(256, 2) void dense_gain_mfma_kernel(DenseView v, co
   const double* __restrict__ T = v.R + size_t(b) * D * D;
   const double* __restrict__ Jg = v.J + size_t(b) * d * d;
   double* __restrict__ F = v.Ft + size_t(b) * d * D;  // [d][W2] used
-  for (int idx = tid; idx < d * W2; idx += 256) {
-    const int a = idx / W2, c = idx % W2;
-    double acc = (c <= d + a) ? p1 * T[size_t(d + a) * D + c] : 0.0;
-    if (c < d) {
-      double s = 0.0;
-      for (int q = c; q < d; ++q) s += Jg[a * d + q] * T[size_t(q) * D + c];
-      acc -= p0 * s;
+  // F[:, d:2d] = p1 T[d:2d, d:2d] (lower triangular block)
+  for (int idx = tid; idx < d * d; idx += 256) {
+    const int a = idx / d, c = idx % d;
+    F[a * W2 + d + c] = (c <= a) ? p1 * T[size_t(d + a) * D + d + c] : 0.0;
+  }
+  // F[:, 0:d] = p1 T[d:2d, 0:d] - p0 J T[0:d, 0:d]   (MFMA, T[0:d,0:d] lower triangular)
+  for (int tile = wv; tile < DD * DD; tile += 4) {
+    const int ta = tile / DD, tc = tile % DD;
+    double4_t acc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = p1 * T[size_t(d + 16 * ta + g + 4 * q) * D + 16 * tc + r];
+    for (int s = 4 * tc; s < d / 4; ++s) {  // rows q >= 16 tc of the triangular block contribute
+      const int qq = 4 * s + g;
+      const double bv = (16 * tc + r <= qq) ? T[size_t(qq) * D + 16 * tc + r] : 0.0;
+      acc = MFMA64(-p0 * Jg[(16 * ta + r) * d + qq], bv, acc);
     }
-    F[idx] = acc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) F[(16 * ta + g + 4 * q) * W2 + 16 * tc + r] = acc[q];
   }
   for (int j = tid; j < d; j += 256) wz[j] = v.z[size_t(b) * d + j];
   __syncthreads();
@@ -778,7 +852,7 @@ __global__ __launch_bounds__(256, 2) void dense_gain_mfma_kernel(DenseView v, co
     for (int q = 0; q < 4; ++q) Sm[(16 * ta + g + 4 * q) * LD + 16 * tb + r] = acc[q];
   }
   __syncthreads();
-  lds_cholesky<d, LD>(Sm, tid);
+  lds_cholesky_blocked<DD, LD>(Sm, tid);
   // one thread per column of F (and one for z): register-resident forward substitution
   if (tid <= W2) {
     double col[d];
