@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="trajectories per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--model", default="dense", choices=["dense", "isotropic"])
+    ap.add_argument("--diag-fixed-dt", type=float, default=0.0,
+                    help="diagnostics only: constant step size, controller bypassed (used with PNODE_ABLATE timing runs)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -136,6 +138,16 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    if args.diag_fixed_dt > 0.0:
+        err_buf = np.zeros(B)
+
+        def diag_attempt(_active):
+            batch.attempt_step(np.full(B, args.diag_fixed_dt), np.ones(B, np.uint8), err_buf)
+            loop.device_ms += batch.last_step_ms()
+            batch.commit(np.ones(B, np.uint8))
+            loop.steps += 1
+
+        loop.attempt = diag_attempt
     for _ in range(args.warmup):
         loop.attempt(active)
     barrier()
@@ -162,9 +174,10 @@ def main():
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         accepted = int(cnt.item())
         # the path's only exchange: gather per-trajectory results (here: current state u, [B, d])
-        u_local = torch.from_numpy(batch.read_mean(0)[:, 0, :].copy()).cuda()
-        gathered = [torch.empty_like(u_local) for _ in range(world)]
-        dist.all_gather(gathered, u_local)
+        from probdiffeq_hip import sharding
+
+        gathered = sharding.gather_results(batch.read_mean(0)[:, 0, :].copy(), device="cuda")
+        assert gathered.shape == (world * B, d)
 
     if rank == 0:
         K = args.steps

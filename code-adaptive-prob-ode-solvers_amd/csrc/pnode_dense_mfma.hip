@@ -242,12 +242,13 @@ struct PanelScratch {
 // needs. On exit the rows hold the reflector vectors, ps.Tpp the final diagonal block, ps.Tf the
 // T-factor.
 template <int DT, int LDV>
-__device__ __forceinline__ void factor_panel(double* rows, const PanelScratch& ps, double* Gm, double t0diag, int tid) {
+__device__ __forceinline__ void factor_panel(double* rows, const PanelScratch& ps, double* Gm, double t0diag, int tid,
+                                             int ablate) {
   constexpr int D = 16 * DT;
   const int rr = tid >> 4, ch = tid & 15;
   ps.Tpp[tid] = (rr == ch) ? t0diag : 0.0;
   __syncthreads();
-  for (int c = 0; c < kNB; ++c) {
+  for (int c = 0; c < ((ablate & 1) ? 0 : kNB); ++c) {
     double xc[DT];
     double part = 0.0;
 #pragma unroll
@@ -390,15 +391,16 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
 
   for (int P = 0; P < DT / 2; ++P) {
     const int c0 = 2 * kNB * P;
+#pragma unroll 8
     for (int idx = tid; idx < 2 * kNB * D; idx += 256) {
       const int i = idx / D, c = idx % D;
       Vx[i * LDV + c] = Mt[size_t(c0 + i) * D + c];
     }
     __syncthreads();
     // ---- panel A
-    factor_panel<DT, LDV>(VA, psA, Gm, sigma * K.qsT[c0 / d][c0 / d], tid);
+    factor_panel<DT, LDV>(VA, psA, Gm, sigma * K.qsT[c0 / d][c0 / d], tid, v.ablate);
     // ---- panel B rows <- reflectors of A (rows live in LDS; natural column order 16 tt + m)
-    {
+    if (!(v.ablate & 4)) {
       double4_t acc = t0_tile(c0 + kNB, c0);
       const double4_t t0v = acc;
 #pragma unroll 8
@@ -423,7 +425,7 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
       __syncthreads();
     }
     // ---- panel B
-    factor_panel<DT, LDV>(VB, psB, Gm, sigma * K.qsT[(c0 + kNB) / d][(c0 + kNB) / d], tid);
+    factor_panel<DT, LDV>(VB, psB, Gm, sigma * K.qsT[(c0 + kNB) / d][(c0 + kNB) / d], tid, v.ablate);
     // ---- diagonal blocks of T
     {
       const int i = tid >> 4, j = tid & 15;
@@ -433,7 +435,7 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
       }
     }
     // ---- trailing strips: both panels in one pass over the rows
-    const int nstrips = DT - 2 * (P + 1);
+    const int nstrips = (v.ablate & 2) ? 0 : DT - 2 * (P + 1);
     for (int st = wv; st < nstrips; st += 4) {
       const int j0 = c0 + 2 * kNB + kNB * st;
       double* __restrict__ rowp = Mt + size_t(j0 + r) * D + 16 * g;
@@ -905,6 +907,7 @@ __global__ __launch_bounds__(256, 2) void dense_strip_update_mfma_kernel(DenseVi
   const int r = lane & 15, g = lane >> 4;
   const double* __restrict__ T = v.R + size_t(b) * D * D;
   const double* __restrict__ Wg = v.Ft + size_t(b) * d * D;
+#pragma unroll 8
   for (int idx = tid; idx < d * W2; idx += 256) Fw[(idx / W2) * LDF + idx % W2] = Wg[idx];
   for (int c = tid; c < W2; c += 256) tv[c] = v.X[size_t(b) * D * d + c];
   __syncthreads();
@@ -957,8 +960,10 @@ __global__ __launch_bounds__(256, 2) void dense_strip_update_mfma_kernel(DenseVi
 #pragma unroll
     for (int s = 0; s < W2 / 4; ++s) Ln[size_t(row) * D + 4 * s + g] = X[s];
     // the remaining columns of these 16 rows are plain (scaled) copies of the triangular factor
+#pragma unroll 4
     for (int rr = 0; rr < 16; ++rr) {
       const int row2 = 16 * st + rr;
+#pragma unroll
       for (int c = W2 + lane; c < D; c += kWave)
         Ln[size_t(row2) * D + c] = (c <= row2) ? pr * T[size_t(row2) * D + c] : 0.0;
     }

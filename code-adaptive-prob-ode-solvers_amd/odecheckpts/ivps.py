@@ -1,0 +1,62 @@
+"""Initial value problems of the reference zoo that the hot path covers.
+
+Counterparts of /root/reference/src/odecheckpts/ivps.py: brusselator (:124-156), van_der_pol (:159-167),
+rigid_body (:20-29), pleiades_1st / pleiades_2nd (:44-99), logistic (:8-17). Each returns
+`(vf, u0, time_span, params)` like the reference, with `vf` a device-backed VectorField that is also
+callable on NumPy arrays as `vf(*u, t=..., p=...)`. Problems outside the benchmark configurations
+(three_body_restricted, neural_ode_mlp) are not provided.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+from probdiffeq_hip import vector_fields as V
+
+
+def logistic():
+    vf = V.logistic(1.0, 1.0)
+    return vf, (np.asarray([0.1]),), (0.0, 10.0), (1.0, 1.0)
+
+
+def rigid_body(*, time_span=(0.0, 10.0)):
+    vf = V.rigid_body()
+    return vf, (np.asarray([1.0, 0.0, 0.9]),), tuple(time_span), (-2.0, 1.25, -0.5)
+
+
+def _pleiades_initial():
+    u0 = np.asarray([3.0, 3.0, -1.0, -3.00, 2.0, -2.00, 2.0, 3.0, -3.0, 2.0, 0.00, 0.0, -4.00, 4.0])
+    du0 = np.asarray([0.0, 0.0, 0.0, 0.00, 0.0, 1.75, -1.5, 0.0, 0.0, 0.0, -1.25, 1.0, 0.00, 0.0])
+    return u0, du0
+
+
+def pleiades_2nd():
+    return V.pleiades_order2(), _pleiades_initial(), (0.0, 3.0)
+
+
+def pleiades_1st():
+    u0, du0 = _pleiades_initial()
+    return V.pleiades_order1(), (np.concatenate([u0, du0]),), (0.0, 3.0), ()
+
+
+def brusselator(N, t0=0.0, tmax=10.0):
+    vf = V.brusselator(int(N))
+    x0 = np.linspace(0, 1, num=int(N))
+    y0 = np.concatenate([np.sin(2 * np.pi * x0) + 1, 3.0 * np.ones(int(N))])
+    return vf, (y0,), (t0, tmax), ()
+
+
+def van_der_pol(mu=10.0**3):
+    return V.van_der_pol_order2(mu), (np.asarray([2.0]), np.asarray([0.0])), (0.0, 6.3)
+
+
+def van_der_pol_first_order(mu=1.0):
+    """First-order form used by the reference's neural-ODE script (experiments/old/7_node/node.py:23-37)."""
+    return V.van_der_pol_order1(mu), (np.asarray([2.0, 0.0]),), (0.0, 6.3), ()
+
+
+def three_body_restricted():
+    raise NotImplementedError("three_body_restricted is outside the benchmark configurations (SURVEY.md section 2, row 5)")
+
+
+def neural_ode_mlp(*, layer_sizes):
+    raise NotImplementedError("neural_ode_mlp is outside the benchmark configurations (SURVEY.md section 2, row 5)")

@@ -66,9 +66,7 @@ def _split(y, i0, i1):
 
 def _concat(parts):
     if hasattr(parts[0], "map_linear"):
-        from .taylor import Series
-
-        return Series([np.concatenate([q.c[k] for q in parts], axis=-1) for k in range(parts[0].order)])
+        return type(parts[0])([np.concatenate([q.c[k] for q in parts], axis=-1) for k in range(parts[0].order)])
     return np.concatenate(parts, axis=-1)
 
 
@@ -79,9 +77,7 @@ def _laplace(w, pad):
         return left - 2.0 * a + right
 
     if hasattr(w, "map_linear"):
-        from .taylor import Series
-
-        return Series([lap(c, pad if k == 0 else 0.0) for k, c in enumerate(w.c)])
+        return type(w)([lap(c, pad if k == 0 else 0.0) for k, c in enumerate(w.c)])
     return lap(w, pad)
 
 

@@ -315,3 +315,51 @@ def test_bad_configuration_raises(hip_lib):
     with pytest.raises(ValueError):
         _backend.Batch(batch=1, d=5, nu=3, ode_order=1, model="isotropic", correction="ts0", strategy="filter",
                        calibration="dynamic", vf_id=V.VF_BRUSSELATOR, vf_params=None)
+
+
+@pytest.mark.parametrize("method", ["ts0-2", "ts0-4"])
+def test_odecheckpts_solve_like_the_reference_test(hip_lib, method):
+    """Port of the reference's only test (tests/test_ivpsolvers.py:31-52): the probabilistic solver agrees
+    with an independent solver on the logistic ODE within sqrt(tol); here the independent solver is scipy
+    (diffrax is not available), and `aux["u0_solve"]` must be present."""
+    from odecheckpts import ivps
+    from odecheckpts import ivpsolvers as l3
+
+    vf, u0, time_span, args = ivps.logistic()
+    dt0, atol, rtol = 0.1, 1e-3, 1e-3
+    save_at = np.linspace(*time_span, num=5)
+    solve1 = l3.solve(method, vf, u0[0], save_at, dt0=dt0, atol=atol, rtol=rtol)
+    solution1, aux1 = solve1(u0, args)
+    assert "u0_solve" in aux1 and "solution" in aux1
+    ts, ys = l3.asolve_scipy("LSODA", vf, time_span, atol=1e-12, rtol=1e-12)(u0, args)
+    truth = np.stack([np.interp(save_at, ts, ys[:, j]) for j in range(ys.shape[1])], axis=1)
+    assert solution1.shape == truth.shape == (5, 1)
+    assert np.allclose(solution1, truth, atol=np.sqrt(atol), rtol=np.sqrt(rtol))
+    # batched call: three initial values at once, each equal to its own single solve
+    u0b = (np.array([[0.1], [0.2], [0.05]]),)
+    solb, _ = solve1(u0b, args)
+    assert solb.shape == (3, 5, 1)
+    assert np.allclose(solb[0], solution1, rtol=1e-12, atol=1e-14)
+
+
+def test_pleiades_second_order_isotropic(hip_lib, golden):
+    """Reference experiment 3 configuration (run_harder.py:42-60): Pleiades, ode_order=2, nu=3, fixedpoint;
+    RMSE against the committed truth solution at the final time is at the level the reference reports."""
+    from odecheckpts import ivps
+    from odecheckpts import ivpsolvers as l3
+
+    vf, u0, (t0, t1) = ivps.pleiades_2nd()
+    g = golden["pleiades"]
+    save_at = np.linspace(t0, t1, 6)
+    tol = 1e-6
+    fn = l3.solve("ts0-3", vf, u0[0], save_at, dt0=0.01, atol=1e-3 * tol, rtol=tol, ode_order=2)
+    sol, aux = fn(u0, ())
+    truth_end = g["ys"][-1][:14]
+    assert np.sqrt(np.mean((sol[-1] - truth_end) ** 2)) < 1e-4
+    cfg = po.SolverConfig(nu=3, model="isotropic", correction="ts0", strategy="fixedpoint", calibration="dynamic")
+    tcs = tcoeffs(vf, list(u0), 3)
+    osol = po.solve_adaptive_save_at(cfg, po.AdaptiveConfig(1e-3 * tol, tol), oracle_problem(vf),
+                                     po.initial_state(cfg, tcs, 0.0), save_at, 0.01)
+    sm = po.markov_marginals_reverse(cfg, osol)[:, 0]
+    assert abs(int(aux["solution"].num_steps[-1]) - int(osol.num_steps[-1])) <= 0.05 * osol.num_steps[-1]
+    assert np.max(np.abs(sol - sm)) < 1e-6
