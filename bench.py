@@ -101,12 +101,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # rehearsal knobs (1-GPU box): PNODE_BENCH_BACKEND=gloo runs the multi-rank branch over CPU tensors,
+    # PNODE_BENCH_DEVICE=0 pins every rank to one GPU. The driver's real runs use nccl (= RCCL), one GPU per rank.
+    backend = os.environ.get("PNODE_BENCH_BACKEND", "nccl")
+    if "PNODE_BENCH_DEVICE" in os.environ:
+        local = int(os.environ["PNODE_BENCH_DEVICE"])
+    tdev = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
         import torch
         import torch.distributed as dist
 
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
@@ -136,7 +145,8 @@ def main():
             import torch
 
             dist.barrier()
-            torch.cuda.synchronize()
+            if backend == "nccl":
+                torch.cuda.synchronize()
 
     if args.diag_fixed_dt > 0.0:
         err_buf = np.zeros(B)
@@ -167,16 +177,16 @@ def main():
     if dist is not None:
         import torch
 
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        cnt = torch.tensor([accepted], dtype=torch.float64, device="cuda")
+        cnt = torch.tensor([accepted], dtype=torch.float64, device=tdev)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         accepted = int(cnt.item())
         # the path's only exchange: gather per-trajectory results (here: current state u, [B, d])
         from probdiffeq_hip import sharding
 
-        gathered = sharding.gather_results(batch.read_mean(0)[:, 0, :].copy(), device="cuda")
+        gathered = sharding.gather_results(batch.read_mean(0)[:, 0, :].copy(), device=tdev)
         assert gathered.shape == (world * B, d)
 
     if rank == 0:
