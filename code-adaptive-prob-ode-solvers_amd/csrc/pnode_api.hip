@@ -597,6 +597,15 @@ int pnode_set_generic_path(pnode_batch* h, int32_t enabled) {
   return PNODE_OK;
 }
 
+// Diagnostics: copy `count` 64-bit words of the X scratch of trajectory b (after the tv head) to the host.
+int pnode_debug_read_scratch(pnode_batch* h, int32_t b, int32_t offset_words, int32_t count, uint64_t* out) {
+  if (!h || !out || !h->dense) return fail(PNODE_EINVAL, "bad argument");
+  const size_t D = h->D, d = h->cfg.d;
+  HIP_TRY(hipMemcpy(out, reinterpret_cast<uint64_t*>(h->dn.X + size_t(b) * D * d) + offset_words, size_t(count) * 8,
+                    hipMemcpyDeviceToHost));
+  return PNODE_OK;
+}
+
 int pnode_set_phase_timing(pnode_batch* h, int32_t enabled) {
   if (!h) return fail(PNODE_EINVAL, "null handle");
   h->phase_timing = enabled != 0;

@@ -237,50 +237,81 @@ struct PanelScratch {
   double* beta;   // [16]
 };
 
+// 1/sqrt(x) and 1/x to full fp64 precision from the hardware estimates + Newton steps (no division
+// sequences on the critical path of the panel sweep).
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const double e = fma(-x * y, y, 1.0);     // 1 - x y^2
+    y = fma(0.5 * y, e, y);
+  }
+  return y;
+}
+__device__ __forceinline__ double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) y = fma(fma(-x, y, 1.0), y, y);
+  return y;
+}
+
 // Row-Householder factorisation of the 16 LDS rows starting at `rows` (stride LDV); one barrier per
 // row. Groups above the pivot row (idle in a textbook sweep) compute the Gram entries the T-factor
-// needs. On exit the rows hold the reflector vectors, ps.Tpp the final diagonal block, ps.Tf the
-// T-factor.
+// needs. The rows are left UNSCALED: reflector c is v_c = [1 ; scl[c] * rows[c]]; consumers scale
+// their 16-wide G / W fragments by scl[] instead. On exit ps.Tpp holds the final diagonal block of T
+// and ps.Tf the compact-WY factor.
 template <int DT, int LDV>
-__device__ __forceinline__ void factor_panel(double* rows, const PanelScratch& ps, double* Gm, double t0diag, int tid,
-                                             int ablate) {
-  constexpr int D = 16 * DT;
+__device__ __forceinline__ void factor_panel(double* rows, const PanelScratch& ps, double* Gm, double* Nm, double t0diag,
+                                             int tid, int ablate) {
   const int rr = tid >> 4, ch = tid & 15;
   ps.Tpp[tid] = (rr == ch) ? t0diag : 0.0;
+  Gm[tid] = 0.0;
+  // each 16-lane group keeps ITS row in registers for the whole sweep; a row is published to LDS
+  // once, when it has received its last update (it is then the next pivot row)
+  double xr[DT];
+#pragma unroll
+  for (int i = 0; i < DT; ++i) xr[i] = rows[rr * LDV + ch + 16 * i];
   __syncthreads();
   for (int c = 0; c < ((ablate & 1) ? 0 : kNB); ++c) {
     double xc[DT];
-    double part = 0.0;
+    double p0 = 0.0, p1 = 0.0, d0 = 0.0, d1 = 0.0;
 #pragma unroll
-    for (int i = 0; i < DT; ++i) {
+    for (int i = 0; i < DT; i += 2) {
       xc[i] = rows[c * LDV + ch + 16 * i];
-      part += xc[i] * xc[i];
+      xc[i + 1] = rows[c * LDV + ch + 16 * (i + 1)];
+      p0 = fma(xc[i], xc[i], p0);
+      p1 = fma(xc[i + 1], xc[i + 1], p1);
+      d0 = fma(xr[i], xc[i], d0);
+      d1 = fma(xr[i + 1], xc[i + 1], d1);
     }
-    const double xx = row16_sum(part);
+    const double xx = row16_sum(p0 + p1);
+    const double dot = row16_sum(d0 + d1);
     const double alpha = ps.Tpp[c * kNB + c];
+    // beta = -sign(alpha) sqrt(alpha^2 + xx); tau = (beta - alpha)/beta = 1 + |alpha| rs; scale = 1/(alpha - beta)
     double tauc = 0.0, scale = 0.0, beta = alpha;
     if (xx != 0.0) {
-      beta = -copysign(sqrt(alpha * alpha + xx), alpha);
-      tauc = (beta - alpha) / beta;
-      scale = 1.0 / (alpha - beta);
+      const double nrm2 = fma(alpha, alpha, xx);
+      const double rs = fast_rsqrt(nrm2);
+      const double sgn = copysign(1.0, alpha);
+      beta = -sgn * nrm2 * rs;
+      tauc = fma(fabs(alpha), rs, 1.0);
+      scale = sgn * rs * fast_rcp(tauc);
     }
-    if (rr != c) {
-      double dpart = 0.0;
+    if (rr > c) {
+      if (tauc != 0.0) {
+        const double tjc = ps.Tpp[rr * kNB + c];
+        const double w = tauc * fma(scale, dot, tjc);
+        const double ws = w * scale;
 #pragma unroll
-      for (int i = 0; i < DT; ++i) dpart += rows[rr * LDV + ch + 16 * i] * xc[i];
-      const double dot = row16_sum(dpart);
-      if (rr > c) {
-        if (tauc != 0.0) {
-          const double tjc = ps.Tpp[rr * kNB + c];
-          const double w = tauc * (tjc + scale * dot);
-          const double ws = w * scale;
-#pragma unroll
-          for (int i = 0; i < DT; ++i) rows[rr * LDV + ch + 16 * i] -= ws * xc[i];
-          if (ch == 0) ps.Tpp[rr * kNB + c] = tjc - w;
-        }
-      } else if (ch == 0) {
-        Gm[rr * kNB + c] = ps.scl[rr] * scale * dot;  // vx_rr . vx_c  (rr < c: row rr is final)
+        for (int i = 0; i < DT; ++i) xr[i] = fma(-ws, xc[i], xr[i]);
+        if (ch == 0) ps.Tpp[rr * kNB + c] = tjc - w;
       }
+      if (rr == c + 1) {
+#pragma unroll
+        for (int i = 0; i < DT; ++i) rows[rr * LDV + ch + 16 * i] = xr[i];
+      }
+    } else if (rr < c) {
+      if (ch == 0) Gm[rr * kNB + c] = dot;  // raw rows[rr] . rows[c]  (row rr is final)
     } else if (ch == 0) {
       ps.beta[c] = beta;
       ps.tau[c] = tauc;
@@ -288,26 +319,36 @@ __device__ __forceinline__ void factor_panel(double* rows, const PanelScratch& p
     }
     __syncthreads();
   }
-  // scale the rows into reflector vectors, finalise the diagonal of T, build the T-factor
-  for (int idx = tid; idx < kNB * D; idx += 256) {
-    const int i = idx / D, cidx = idx % D;
-    rows[i * LDV + cidx] *= ps.scl[i];
-  }
-  if (tid < kNB) {
-    ps.Tpp[tid * kNB + tid] = ps.beta[tid];
-    const int i = tid;
-    double row[kNB];
+  // T-factor: Tf = (D^-1 + striu(V V^T))^-1 = (I + N)^-1 D,  N = D striu(G), via the nilpotent product
+  // (I + N)^-1 = (I - N)(I + N^2)(I + N^4)(I + N^8); every thread owns one entry (i, j) = (rr, ch).
+  {
+    const int i = rr, j = ch;
+    double* A = ps.Tf;  // accumulates (I - N)(I + N^2)...
+    double* Pm = Nm;    // current power of N
+    const double si = ps.scl[i], sj = ps.scl[j];
+    const double nij = (j > i) ? ps.tau[i] * si * sj * Gm[i * kNB + j] : 0.0;
+    Pm[tid] = nij;
+    A[tid] = ((i == j) ? 1.0 : 0.0) - nij;
+    if (tid < kNB) ps.Tpp[tid * kNB + tid] = ps.beta[tid];
+    __syncthreads();
+#pragma unroll 1
+    for (int it = 0; it < 3; ++it) {
+      double p2 = 0.0;
 #pragma unroll
-    for (int j = 0; j < kNB; ++j) {
-      const double tj = ps.tau[j];
-      double acc = 0.0;
+      for (int m = 0; m < kNB; ++m) p2 = fma(Pm[i * kNB + m], Pm[m * kNB + j], p2);
+      __syncthreads();
+      Pm[tid] = p2;
+      __syncthreads();
+      double ap = A[tid];
 #pragma unroll
-      for (int m = 0; m < kNB; ++m)
-        if (m < j) acc += row[m] * Gm[m * kNB + j];
-      row[j] = (i == j) ? tj : ((i < j) ? -tj * acc : 0.0);
+      for (int m = 0; m < kNB; ++m) ap = fma(A[i * kNB + m], Pm[m * kNB + j], ap);
+      __syncthreads();
+      A[tid] = ap;
+      __syncthreads();
     }
-#pragma unroll
-    for (int j = 0; j < kNB; ++j) ps.Tf[i * kNB + j] = row[j];
+    const double tf = A[tid] * ps.tau[j];
+    __syncthreads();
+    A[tid] = tf;
   }
   __syncthreads();
 }
@@ -315,9 +356,12 @@ __device__ __forceinline__ void factor_panel(double* rows, const PanelScratch& p
 // One panel's reflectors applied to a register strip X (HBM layout). Writes T[J][P] = T0 - W.
 template <int DT, int LDV>
 __device__ __forceinline__ void apply_panel_to_strip(double (&X)[4 * DT], const double* __restrict__ Vp,
-                                                     const double* __restrict__ Tfp, double4_t t0v,
-                                                     double* __restrict__ Tout, int r, int g) {
-  double4_t a0 = t0v, a1 = {0.0, 0.0, 0.0, 0.0}, a2 = a1, a3 = a1;
+                                                     const double* __restrict__ Tfp, const double* __restrict__ sclp,
+                                                     double4_t t0v, double* __restrict__ Tout, int r, int g) {
+  double4_t a0 = {0.0, 0.0, 0.0, 0.0}, a1 = a0, a2 = a0, a3 = a0;
+  double4_t sc;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) sc[q] = sclp[g + 4 * q];
 #pragma unroll
   for (int T = 0; T < DT / 4; ++T) {
 #pragma unroll
@@ -330,12 +374,13 @@ __device__ __forceinline__ void apply_panel_to_strip(double (&X)[4 * DT], const 
     }
     __builtin_amdgcn_sched_barrier(0);  // keep the LDS operand loads of later super-tiles from being hoisted
   }
-  const double4_t acc = (a0 + a1) + (a2 + a3);
+  const double4_t acc = t0v + ((a0 + a1) + (a2 + a3)) * sc;  // G = T0 + (X raw^T) diag(scl)
   double4_t w4 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) w4 = MFMA64(Tfp[(4 * kk + g) * kNB + r], acc[kk], w4);
 #pragma unroll
   for (int q = 0; q < 4; ++q) Tout[g + 4 * q] = t0v[q] - w4[q];
+  w4 = w4 * sc;  // the update below multiplies by the unscaled rows
   const int coff = 16 * (r & 3) + (r >> 2);
 #pragma unroll
   for (int T = 0; T < DT / 4; ++T) {
@@ -363,6 +408,7 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
   __shared__ double TppS[2 * kNB * kNB];
   __shared__ double TfS[2 * kNB * kNB];
   __shared__ double Gm[kNB * kNB];
+  __shared__ double Nm[kNB * kNB];
   __shared__ double small[6 * kNB];
 
   const int b = blockIdx.x;
@@ -374,6 +420,11 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
   double* __restrict__ T = v.R + size_t(b) * D * D;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
+  if (v.ablate & 64) {
+    // diagnostics: de-phase the co-resident workgroups of a CU (second dispatch wave starts later)
+    if ((blockIdx.x >> 8) & 1)
+      for (int i = 0; i < (v.ablate >> 8); ++i) __builtin_amdgcn_s_sleep(127);
+  }
   PanelScratch psA{TppS, TfS, small, small + 16, small + 32};
   PanelScratch psB{TppS + 256, TfS + 256, small + 48, small + 64, small + 80};
   double* VA = Vx;
@@ -389,22 +440,47 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
     return t;
   };
 
+  const bool stamp = (v.ablate & 128) != 0;
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tprev = stamp ? __builtin_amdgcn_s_memtime() : 0ull;
+  auto lap = [&](int slot) {
+    if (stamp) {
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      tacc[slot] += now - tprev;
+      tprev = now;
+    }
+  };
   for (int P = 0; P < DT / 2; ++P) {
     const int c0 = 2 * kNB * P;
-#pragma unroll 8
-    for (int idx = tid; idx < 2 * kNB * D; idx += 256) {
-      const int i = idx / D, c = idx % D;
-      Vx[i * LDV + c] = Mt[size_t(c0 + i) * D + c];
+    {
+      constexpr int NL = 2 * kNB * D / 256;
+      double tmp[NL];
+#pragma unroll
+      for (int e = 0; e < NL; ++e) tmp[e] = Mt[size_t(c0) * D + tid + 256 * e];
+#pragma unroll
+      for (int e = 0; e < NL; ++e) {
+        const int idx = tid + 256 * e;
+        Vx[(idx / D) * LDV + idx % D] = tmp[e];
+      }
     }
     __syncthreads();
+    lap(0);
     // ---- panel A
-    factor_panel<DT, LDV>(VA, psA, Gm, sigma * K.qsT[c0 / d][c0 / d], tid, v.ablate);
+    factor_panel<DT, LDV>(VA, psA, Gm, Nm, sigma * K.qsT[c0 / d][c0 / d], tid, v.ablate);
+    lap(1);
     // ---- panel B rows <- reflectors of A (rows live in LDS; natural column order 16 tt + m)
     if (!(v.ablate & 4)) {
-      double4_t acc = t0_tile(c0 + kNB, c0);
-      const double4_t t0v = acc;
+      const double4_t t0v = t0_tile(c0 + kNB, c0);
+      double4_t ar0 = {0.0, 0.0, 0.0, 0.0}, ar1 = ar0;
 #pragma unroll 8
-      for (int s = 0; s < D / 4; ++s) acc = MFMA64(VA[r * LDV + 4 * s + g], VB[r * LDV + 4 * s + g], acc);
+      for (int s = 0; s < D / 4; s += 2) {
+        ar0 = MFMA64(VA[r * LDV + 4 * s + g], VB[r * LDV + 4 * s + g], ar0);
+        ar1 = MFMA64(VA[r * LDV + 4 * s + 4 + g], VB[r * LDV + 4 * s + 4 + g], ar1);
+      }
+      double4_t sc;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sc[q] = psA.scl[g + 4 * q];
+      const double4_t acc = t0v + (ar0 + ar1) * sc;
       double4_t w4 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) w4 = MFMA64(psA.Tf[(4 * kk + g) * kNB + r], acc[kk], w4);
@@ -412,6 +488,7 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
 #pragma unroll
         for (int q = 0; q < 4; ++q) T[size_t(c0 + kNB + r) * D + c0 + g + 4 * q] = t0v[q] - w4[q];
       }
+      w4 = w4 * sc;
       __syncthreads();  // every wave has read all of B before anyone overwrites its tiles
       for (int tt = wv; tt < DT; tt += 4) {
         double4_t c4;
@@ -424,8 +501,10 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
       }
       __syncthreads();
     }
+    lap(2);
     // ---- panel B
-    factor_panel<DT, LDV>(VB, psB, Gm, sigma * K.qsT[(c0 + kNB) / d][(c0 + kNB) / d], tid, v.ablate);
+    factor_panel<DT, LDV>(VB, psB, Gm, Nm, sigma * K.qsT[(c0 + kNB) / d][(c0 + kNB) / d], tid, v.ablate);
+    lap(3);
     // ---- diagonal blocks of T
     {
       const int i = tid >> 4, j = tid & 15;
@@ -434,6 +513,7 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
         T[size_t(c0 + kNB + i) * D + c0 + kNB + j] = psB.Tpp[i * kNB + j];
       }
     }
+    lap(4);
     // ---- trailing strips: both panels in one pass over the rows
     const int nstrips = (v.ablate & 2) ? 0 : DT - 2 * (P + 1);
     for (int st = wv; st < nstrips; st += 4) {
@@ -449,8 +529,8 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
           X[16 * T4 + e + 1] = t2.y;
         }
       double* Trow = T + size_t(j0 + r) * D + c0;
-      apply_panel_to_strip<DT, LDV>(X, VA, psA.Tf, t0_tile(j0, c0), Trow, r, g);
-      apply_panel_to_strip<DT, LDV>(X, VB, psB.Tf, t0_tile(j0, c0 + kNB), Trow + kNB, r, g);
+      apply_panel_to_strip<DT, LDV>(X, VA, psA.Tf, psA.scl, t0_tile(j0, c0), Trow, r, g);
+      apply_panel_to_strip<DT, LDV>(X, VB, psB.Tf, psB.scl, t0_tile(j0, c0 + kNB), Trow + kNB, r, g);
 #pragma unroll
       for (int T4 = 0; T4 < DT / 4; ++T4)
 #pragma unroll
@@ -461,7 +541,13 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
           *reinterpret_cast<double2*>(rowp + 64 * T4 + e) = t2;
         }
     }
+    lap(5);
     __syncthreads();
+    lap(6);
+  }
+  if (stamp && lane == 0) {
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(v.X + size_t(b) * D * d) + 512 + wv * 8;
+    for (int i = 0; i < 8; ++i) dbg[i] = tacc[i];
   }
 }
 
@@ -907,8 +993,18 @@ __global__ __launch_bounds__(256, 2) void dense_strip_update_mfma_kernel(DenseVi
   const int r = lane & 15, g = lane >> 4;
   const double* __restrict__ T = v.R + size_t(b) * D * D;
   const double* __restrict__ Wg = v.Ft + size_t(b) * d * D;
-#pragma unroll 8
-  for (int idx = tid; idx < d * W2; idx += 256) Fw[(idx / W2) * LDF + idx % W2] = Wg[idx];
+  {
+    constexpr int NL = d * W2 / 512;  // double2 loads per thread
+    double2 tmp[NL];
+#pragma unroll
+    for (int e = 0; e < NL; ++e) tmp[e] = reinterpret_cast<const double2*>(Wg)[tid + 256 * e];
+#pragma unroll
+    for (int e = 0; e < NL; ++e) {
+      const int idx = 2 * (tid + 256 * e);
+      Fw[(idx / W2) * LDF + idx % W2] = tmp[e].x;
+      Fw[(idx / W2) * LDF + idx % W2 + 1] = tmp[e].y;
+    }
+  }
   for (int c = tid; c < W2; c += 256) tv[c] = v.X[size_t(b) * D * d + c];
   __syncthreads();
   const size_t sB = size_t(v.B);
@@ -960,12 +1056,20 @@ __global__ __launch_bounds__(256, 2) void dense_strip_update_mfma_kernel(DenseVi
 #pragma unroll
     for (int s = 0; s < W2 / 4; ++s) Ln[size_t(row) * D + 4 * s + g] = X[s];
     // the remaining columns of these 16 rows are plain (scaled) copies of the triangular factor
-#pragma unroll 4
-    for (int rr = 0; rr < 16; ++rr) {
-      const int row2 = 16 * st + rr;
+    {
+      constexpr int NC = (D - W2) / kWave;  // column chunks per row
+      double tmp[16 * NC];
 #pragma unroll
-      for (int c = W2 + lane; c < D; c += kWave)
-        Ln[size_t(row2) * D + c] = (c <= row2) ? pr * T[size_t(row2) * D + c] : 0.0;
+      for (int rr = 0; rr < 16; ++rr)
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) {
+          const int row2 = 16 * st + rr, c = W2 + lane + kWave * cc;
+          tmp[rr * NC + cc] = (c <= row2) ? pr * T[size_t(row2) * D + c] : 0.0;
+        }
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr)
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) Ln[size_t(16 * st + rr) * D + W2 + lane + kWave * cc] = tmp[rr * NC + cc];
     }
   }
   if (blockIdx.x == 0) {

@@ -143,6 +143,9 @@ int pnode_smooth_checkpoint_means(pnode_batch* h, const int32_t* num_filled, dou
 /* Timing of the device work of the most recent attempt_step (HIP events on the handle's stream),
  * in milliseconds; used by bench.py for the roofline line. */
 int pnode_last_step_ms(pnode_batch* h, float* ms_out);
+/* Diagnostics (dense): raw 64-bit words of a trajectory's scratch area (in-kernel cycle stamps of
+ * timing-only builds, PNODE_ABLATE & 128). Never part of a result. */
+int pnode_debug_read_scratch(pnode_batch* h, int32_t b, int32_t offset_words, int32_t count, uint64_t* out);
 /* Dense model only: 1 forces the generic (non-MFMA) kernels even where the MFMA fast path applies
  * (A/B testing of the two device paths; both are HIP, neither is a CPU fallback). */
 int pnode_set_generic_path(pnode_batch* h, int32_t enabled);
