@@ -53,6 +53,21 @@ def algorithmic_flops_lq(D):
     return 2.0 * D**3
 
 
+def measured_traffic(kernel_prefix, batch):
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary
+    (profiles/r01_pmc_summary.json, produced on an MI355X by scripts/collect_profile.sh with separate
+    --pmc passes; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md), scaled to this batch."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    try:
+        data = json.load(open(path))
+    except OSError:
+        return None
+    for name, v in data.items():
+        if name.startswith(kernel_prefix) and "hbm_bytes_per_launch" in v:
+            return v["hbm_bytes_per_launch"] * batch / 1024.0  # the profile run uses 1024 trajectories
+    return None
+
+
 def cpu_baseline(seconds=15.0, sample=2):
     """The NumPy oracle (kind 'port') on a bounded sample of the same workload, on this host's cores."""
     import pn_oracle as po
@@ -215,7 +230,9 @@ def main():
             flops = algorithmic_flops_lq(D) * B
             achieved = flops / (lq_ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None, "kernel": "dense_lq_kernel",
+                               "frac": achieved / FP64_PEAK_TFLOPS, "traffic": measured_traffic("dense_lq2_mfma_kernel", B),
+                               "traffic_source": "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
+                               "kernel": "dense_lq2_mfma_kernel<16>", "algorithmic_flops_per_launch": flops,
                                "phase_ms": {"begin": phase[0] / K, "lq_input": phase[1] / K, "lq": phase[2] / K,
                                             "correct": phase[3] / K}}
         else:
