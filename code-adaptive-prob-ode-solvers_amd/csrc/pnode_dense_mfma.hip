@@ -398,9 +398,11 @@ __device__ __forceinline__ void apply_panel_to_strip(double (&X)[4 * DT], const 
   }
 }
 
-template <int DT>
+// FIRST = true : pass 0 only, reading the state factor L (Mt formed on the fly), writing Mt rows 32.. and T
+// FIRST = false: passes 1 .. DT/2 - 1 from Mt.   (FIRST = false with first_pass = 0: all passes from Mt)
+template <int DT, bool FIRST>
 __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, const StepArg* __restrict__ args,
-                                                             const IwpConst* __restrict__ Kc) {
+                                                             const IwpConst* __restrict__ Kc, int first_pass) {
   static_assert(DT % 4 == 0, "the HBM strip layout needs D % 64 == 0");
   constexpr int D = 16 * DT;
   constexpr int LDV = D + 1;  // 2*LDV = 2 (mod 64) dwords: conflict-free A-operand reads in the G phase
@@ -425,6 +427,20 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
     if ((blockIdx.x >> 8) & 1)
       for (int i = 0; i < (v.ablate >> 8); ++i) __builtin_amdgcn_s_sleep(127);
   }
+  // pass 0 reads the state factor L directly: Mt = (Abar P^-1 (x) I) L is formed on the fly (no separate
+  // kernel, no extra HBM round trip); coef[i][k] = Abar[i][k] / p_k
+  __shared__ double coef[kMaxN * kMaxN];
+  constexpr bool fused = FIRST;
+  const StepArg sarg = args[b];
+  const double* __restrict__ Lsrc = v.U + (size_t(sarg.src) * v.B + b) * D * D;
+  const int nn = v.n;
+  if (FIRST && tid == 0) {
+    double pl[kMaxN], pil[kMaxN];
+    precond_rt(nn, sarg.dt, K, pl, pil);
+    for (int i = 0; i < nn; ++i)
+      for (int k = 0; k < nn; ++k) coef[i * kMaxN + k] = (k >= i) ? K.a[i][k] * pil[k] : 0.0;
+  }
+  __syncthreads();
   PanelScratch psA{TppS, TfS, small, small + 16, small + 32};
   PanelScratch psB{TppS + 256, TfS + 256, small + 48, small + 64, small + 80};
   double* VA = Vx;
@@ -450,11 +466,22 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
       tprev = now;
     }
   };
-  for (int P = 0; P < DT / 2; ++P) {
+  for (int P = FIRST ? 0 : first_pass; P < (FIRST ? 1 : DT / 2); ++P) {
     const int c0 = 2 * kNB * P;
     {
       constexpr int NL = 2 * kNB * D / 256;
       double tmp[NL];
+      if constexpr (fused) {
+#pragma unroll
+        for (int e = 0; e < NL; ++e) {
+          const int idx = tid + 256 * e;
+          const int row = idx / D, cidx = idx % D;  // rows 0..31 lie in derivative block 0 or (d == 16) 0 and 1
+          const int ib = row / d, q = row % d;
+          double acc = 0.0;
+          for (int k = ib; k < nn; ++k) acc = fma(coef[ib * kMaxN + k], Lsrc[size_t(k * d + q) * D + cidx], acc);
+          tmp[e] = acc;
+        }
+      } else
 #pragma unroll
       for (int e = 0; e < NL; ++e) tmp[e] = Mt[size_t(c0) * D + tid + 256 * e];
 #pragma unroll
@@ -520,6 +547,25 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
       const int j0 = c0 + 2 * kNB + kNB * st;
       double* __restrict__ rowp = Mt + size_t(j0 + r) * D + 16 * g;
       double X[4 * DT];
+      if constexpr (fused) {
+        const int ib = j0 / d, q = (j0 + r) % d;
+#pragma unroll
+        for (int T4 = 0; T4 < DT / 4; ++T4) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) X[16 * T4 + e] = 0.0;
+#pragma unroll 1
+          for (int k = ib; k < nn; ++k) {
+            const double ck = coef[ib * kMaxN + k];
+            const double* __restrict__ lrow = Lsrc + size_t(k * d + q) * D + 16 * g + 64 * T4;
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) {
+              const double2 t2 = *reinterpret_cast<const double2*>(lrow + e);
+              X[16 * T4 + e] = fma(ck, t2.x, X[16 * T4 + e]);
+              X[16 * T4 + e + 1] = fma(ck, t2.y, X[16 * T4 + e + 1]);
+            }
+          }
+        }
+      } else
 #pragma unroll
       for (int T4 = 0; T4 < DT / 4; ++T4)
 #pragma unroll
@@ -1124,12 +1170,16 @@ static void launch_mfma(const DenseView& v, const StepArg* args, const IwpConst*
   auto mark = [&](int i) {
     if (ev) (void)hipEventRecord(ev->ev[i], s);
   };
-  hipLaunchKernelGGL(dense_mt_kernel, dim3(64, v.B), dim3(256), 0, s, v, args, K);
+  if (v.ablate & (8 | 1024)) hipLaunchKernelGGL(dense_mt_kernel, dim3(64, v.B), dim3(256), 0, s, v, args, K);
   mark(2);
-  if (v.ablate & 8)
+  if (v.ablate & 8) {
     hipLaunchKernelGGL((dense_lq_mfma_kernel<DT>), dim3(v.B), dim3(256), 0, s, v, args, K);
-  else
-    hipLaunchKernelGGL((dense_lq2_mfma_kernel<DT>), dim3(v.B), dim3(256), 0, s, v, args, K);
+  } else if (v.ablate & 1024) {
+    hipLaunchKernelGGL((dense_lq2_mfma_kernel<DT, false>), dim3(v.B), dim3(256), 0, s, v, args, K, 0);
+  } else {
+    hipLaunchKernelGGL((dense_lq2_mfma_kernel<DT, true>), dim3(v.B), dim3(256), 0, s, v, args, K, 0);
+    hipLaunchKernelGGL((dense_lq2_mfma_kernel<DT, false>), dim3(v.B), dim3(256), 0, s, v, args, K, 1);
+  }
   mark(3);
   constexpr int d = 16 * DD, W2 = 2 * d;
   if (!(v.ablate & 16)) {
