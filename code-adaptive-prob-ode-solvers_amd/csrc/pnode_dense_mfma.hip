@@ -1039,6 +1039,16 @@ __global__ __launch_bounds__(256, 2) void dense_strip_update_mfma_kernel(DenseVi
   const int r = lane & 15, g = lane >> 4;
   const double* __restrict__ T = v.R + size_t(b) * D * D;
   const double* __restrict__ Wg = v.Ft + size_t(b) * d * D;
+  const bool stamp = (v.ablate & 128) != 0;
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tprev = stamp ? __builtin_amdgcn_s_memtime() : 0ull;
+  auto lap = [&](int slot) {
+    if (stamp) {
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      tacc[slot] += now - tprev;
+      tprev = now;
+    }
+  };
   {
     constexpr int NL = d * W2 / 512;  // double2 loads per thread
     double2 tmp[NL];
@@ -1053,6 +1063,7 @@ __global__ __launch_bounds__(256, 2) void dense_strip_update_mfma_kernel(DenseVi
   }
   for (int c = tid; c < W2; c += 256) tv[c] = v.X[size_t(b) * D * d + c];
   __syncthreads();
+  lap(0);
   const size_t sB = size_t(v.B);
   double* mdst = v.mean + (size_t(arg.dst) * sB + b) * D;
   double* __restrict__ Ln = v.U + (size_t(arg.dst) * sB + b) * D * D;
@@ -1079,6 +1090,7 @@ __global__ __launch_bounds__(256, 2) void dense_strip_update_mfma_kernel(DenseVi
     mpart += __shfl_xor(mpart, 16, kWave);
     mpart += __shfl_xor(mpart, 32, kWave);
     if (g == 0) mdst[row] -= mpart;
+    lap(1);
     double4_t yT[DD];
 #pragma unroll
     for (int ta = 0; ta < DD; ++ta) {
@@ -1117,6 +1129,11 @@ __global__ __launch_bounds__(256, 2) void dense_strip_update_mfma_kernel(DenseVi
 #pragma unroll
         for (int cc = 0; cc < NC; ++cc) Ln[size_t(16 * st + rr) * D + W2 + lane + kWave * cc] = tmp[rr * NC + cc];
     }
+    lap(4);
+  }
+  if (stamp && lane == 0 && blockIdx.x == 1) {
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(v.X + size_t(b) * D * d) + 1024 + wv * 8;
+    for (int i = 0; i < 8; ++i) dbg[i] = tacc[i];
   }
   if (blockIdx.x == 0) {
     // rows 0 .. 63 of the state are covered by this block when d <= 64: error norm over u = m[0]

@@ -1,0 +1,122 @@
+"""Full-size (BASELINE configuration) checks through size-independent properties."""
+
+import numpy as np
+import pn_oracle as po
+import pytest
+from helpers import brusselator_y0, oracle_problem, tcoeffs
+from probdiffeq_hip import ivpsolve, ivpsolvers, taylor
+from probdiffeq_hip import vector_fields as V
+from probdiffeq_hip.impl import impl
+
+pytestmark = pytest.mark.gpu
+
+N, NU, TOL, DT0 = 32, 3, 1e-6, 0.01
+
+
+def _phase_batch(B, idx=None):
+    x = np.linspace(0.0, 1.0, N)
+    b = np.arange(B) if idx is None else np.asarray(idx)
+    phases = 2.0 * np.pi * b / B
+    return np.concatenate([1.0 + np.sin(2 * np.pi * x[None, :] + phases[:, None]), 3.0 * np.ones((len(b), N))], axis=1)
+
+
+def _dense_solver():
+    impl.select("dense", ode_shape=(2 * N,))
+    return ivpsolvers.solver_dynamic(ivpsolvers.strategy_filter(ivpsolvers.prior_ibm(NU), ivpsolvers.correction_ts1()))
+
+
+def _run_attempts(vf, y0, num_attempts):
+    solver = _dense_solver()
+    tcs = taylor.odejet_padded_scan(vf, [y0], num=NU)
+    init = solver.initial_condition(tcs, 1.0)
+    B = y0.shape[0]
+    batch = ivpsolve._make_batch(vf, init, solver, 1)
+    batch.set_initial(init.tcoeffs, np.zeros(B), init.output_scale)
+    batch.set_tolerances(TOL, TOL)
+    loop = ivpsolve._AdaptiveLoop(batch, ivpsolve.adaptive(solver, atol=TOL, rtol=TOL), np.zeros(B), DT0)
+    for _ in range(num_attempts):
+        loop.attempt(np.ones(B, dtype=bool))
+    return batch, loop, tcs
+
+
+def test_headline_batch_is_composition_invariant_and_matches_oracle(hip_lib):
+    """C4 (B = 1024 dense EKF1): a trajectory's result must not depend on what else is in the batch
+    (bit-identical in a batch of 1024 and in a batch of 5), and must match the oracle."""
+    vf = V.brusselator(N)
+    B = 1024
+    pick = [0, 1, 333, 777, 1023]
+    big, loop_big, tcs_big = _run_attempts(vf, _phase_batch(B), 12)
+    small, loop_small, _ = _run_attempts(vf, _phase_batch(B, pick), 12)
+    m_big, m_small = big.read_mean(0), small.read_mean(0)
+    assert np.array_equal(loop_big.steps[pick], loop_small.steps)
+    assert np.array_equal(loop_big.t[pick], loop_small.t)
+    assert np.array_equal(m_big[pick], m_small)
+    assert np.array_equal(big.read_output_scale(0)[pick], small.read_output_scale(0))
+    assert loop_big.steps.min() >= 4  # the initial transient rejects a few attempts
+    # oracle on three of them, replaying the same controller
+    cfg = po.SolverConfig(nu=NU, model="dense", correction="ts1", strategy="filter", calibration="dynamic")
+    acfg = po.AdaptiveConfig(TOL, TOL)
+    prob = oracle_problem(vf)
+    for b in (0, 333, 1023):
+        ast = po.adaptive_init(po.initial_state(cfg, [c[b] for c in tcs_big], 0.0), DT0)
+        attempts = 0
+        while attempts < 12:
+            before = ast.num_attempts
+            ast = po.rejection_loop(cfg, acfg, prob, ast, np.inf)
+            attempts = ast.num_attempts
+            if attempts > 12:
+                break
+        # compare at the last state both have reached: replay exactly loop_big.steps[b] accepted steps
+        ast = po.adaptive_init(po.initial_state(cfg, [c[b] for c in tcs_big], 0.0), DT0)
+        for _ in range(int(loop_big.steps[b])):
+            ast = po.rejection_loop(cfg, acfg, prob, ast, np.inf)
+        assert abs(ast.step_from.t - loop_big.t[b]) <= 1e-9 * loop_big.t[b]  # dt inherits the ~1e-8 noise of the error norm
+        ref = ast.step_from.mean
+        assert np.max(np.abs(m_big[b, 0] - ref[0])) / np.max(np.abs(ref[0])) < 1e-10
+        assert np.max(np.abs(m_big[b, 1] - ref[1])) / np.max(np.abs(ref[1])) < 1e-8
+
+
+def test_noise_free_measurement_property_full_batch(hip_lib):
+    """After a correction the innovation covariance must vanish: H Sigma H^T = (H L)(H L)^T ~ 0 relative to
+    the predicted one, and Sigma = R^T R stays symmetric PSD with rank <= D - d (checked on a sample)."""
+    vf = V.brusselator(N)
+    B = 1024
+    batch, loop, _ = _run_attempts(vf, _phase_batch(B), 6)
+    R = batch.read_factor(0)  # (B, D, D) with Sigma = R^T R
+    means = batch.read_mean(0)
+    d, D = 2 * N, (NU + 1) * 2 * N
+    prob = oracle_problem(vf)
+    for b in (0, 511, 1023):
+        L = R[b].T
+        J = prob.jac(means[b][:1], 0.0)[:, 0, :]
+        H = np.zeros((d, D))
+        H[:, d:2 * d] = np.eye(d)
+        H[:, :d] = -J
+        HL = H @ L
+        # the corrected mean sits on the ODE manifold of the linearisation, the factor carries no mass along H
+        assert np.linalg.norm(HL) < 1e-6 * np.linalg.norm(H) * np.linalg.norm(L)
+        sv = np.linalg.svd(L, compute_uv=False)
+        assert np.sum(sv > 1e-9 * sv[0]) <= D - d + 2
+
+
+def test_isotropic_full_batch_contains_the_reference_trajectory(hip_lib, golden):
+    """1024 isotropic EKF0 fixed-point solves of the reference's experiment-4 configuration in one batch
+    (phase family); trajectory 0 IS the reference IVP: accepted steps bit-exact, checkpoint means 1e-9."""
+    g = golden["brusselator"]
+    vf = V.brusselator(N)
+    B = 1024
+    impl.select("isotropic", ode_shape=(2 * N,))
+    solver = ivpsolvers.solver_dynamic(ivpsolvers.strategy_fixedpoint(ivpsolvers.prior_ibm(4), ivpsolvers.correction_ts0()))
+    y0 = _phase_batch(B)
+    assert np.max(np.abs(y0[0] - brusselator_y0(N))) == 0.0
+    tcs = taylor.odejet_unroll(vf, [y0], num=4)
+    sol = ivpsolve.solve_adaptive_save_at(vf, solver.initial_condition(tcs, 1.0), save_at=g["ts"], dt0=0.01,
+                                          adaptive_solver=ivpsolve.adaptive(solver, atol=1e-8, rtol=1e-8))
+    i = list(g["N"]).index(N)
+    assert int(sol.num_steps[0, -1]) == int(g["num_steps_checkpoint"][i])
+    assert np.max(np.abs(sol.u[0] - g[f"ys_N{N}"])) < 1e-9
+    assert sol.u.shape == (B, 200, 2 * N) and np.all(np.isfinite(sol.u))
+    # phase symmetry of the problem family is NOT exact (Dirichlet pads), but every trajectory must stay bounded
+    assert np.max(np.abs(sol.u)) < 10.0
+    # step counts vary smoothly over the family
+    assert sol.num_steps[:, -1].min() > 5000 and sol.num_steps[:, -1].max() < 30000
