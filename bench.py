@@ -68,36 +68,48 @@ def measured_traffic(kernel_prefix, batch):
     return None
 
 
-def cpu_baseline(seconds=15.0, sample=2):
-    """The NumPy oracle (kind 'port') on a bounded sample of the same workload, on this host's cores."""
+def cpu_baseline(seconds=15.0):
+    """The oracle ("port") timed on this host's cores on a bounded sample of the same workload:
+    oracle/pn_oracle_c.c (C restatement of oracle/pn_oracle.py, checked against it in tests/test_oracle_c.py),
+    OpenMP with one trajectory per thread, every thread running the adaptive loop for `seconds`."""
+    import ctypes as C
+
+    try:
+        threads = len(os.sched_getaffinity(0))
+    except AttributeError:
+        threads = os.cpu_count() or 1
+    vf, tcs = problem_batch(threads, 0, 1024)
+    tc = np.ascontiguousarray(np.stack(tcs, axis=1))
+    path = os.path.join(ROOT, "oracle", "libpn_oracle_c.so")
+    if os.path.exists(path):
+        lib = C.CDLL(path)
+        dp = C.POINTER(C.c_double)
+        lib.pnoc_bench_brusselator.restype = C.c_double
+        lib.pnoc_bench_brusselator.argtypes = [C.c_int, C.c_int, C.c_int, dp, C.c_double, C.c_double, C.c_double, C.c_int,
+                                               C.POINTER(C.c_long), C.POINTER(C.c_long)]
+        acc, att = C.c_long(), C.c_long()
+        el = lib.pnoc_bench_brusselator(N_SPATIAL, NU, threads, tc.ctypes.data_as(dp), TOL, DT0, seconds, threads,
+                                        C.byref(acc), C.byref(att))
+        return {"value": acc.value / el, "unit": "accepted steps/s", "cores": int(threads), "kind": "port",
+                "sample": f"oracle/pn_oracle_c.c (OpenMP, one trajectory per thread), {threads} trajectories of the same "
+                          f"batch for {el:.1f}s: {acc.value} accepted / {att.value} attempted steps; "
+                          f"{acc.value / el / threads:.1f} steps/s per core; host reports {os.cpu_count()} cpus"}
+    # fallback: NumPy oracle, single process
     import pn_oracle as po
     from helpers import oracle_problem
 
-    vf, tcs = problem_batch(sample, 0, 1024)
     cfg = po.SolverConfig(nu=NU, model="dense", correction="ts1", strategy="filter", calibration="dynamic")
     acfg = po.AdaptiveConfig(TOL, TOL)
     prob = oracle_problem(vf)
-    accepted = attempts = 0
+    accepted = 0
     t0 = time.perf_counter()
-    for b in range(sample):
-        ast = po.adaptive_init(po.initial_state(cfg, [c[b] for c in tcs], 0.0), DT0)
-        budget = seconds / sample
-        tb = time.perf_counter()
-        while time.perf_counter() - tb < budget:
-            before = ast.num_attempts
-            ast = po.rejection_loop(cfg, acfg, prob, ast, np.inf)
-            accepted += 1
-            attempts += ast.num_attempts - before
+    ast = po.adaptive_init(po.initial_state(cfg, [c[0] for c in tcs], 0.0), DT0)
+    while time.perf_counter() - t0 < seconds:
+        ast = po.rejection_loop(cfg, acfg, prob, ast, np.inf)
+        accepted += 1
     el = time.perf_counter() - t0
-    try:
-        from threadpoolctl import threadpool_info
-
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-    except Exception:
-        cores = os.cpu_count()
-    return {"value": accepted / el, "unit": "accepted steps/s", "cores": int(cores), "kind": "port",
-            "sample": f"NumPy oracle (oracle/pn_oracle.py), {sample} trajectories of the same batch, "
-                      f"{accepted} accepted / {attempts} attempted steps in {el:.1f}s; host has {os.cpu_count()} cores"}
+    return {"value": accepted / el, "unit": "accepted steps/s", "cores": 1, "kind": "port",
+            "sample": f"NumPy oracle (oracle/pn_oracle.py), 1 trajectory, {accepted} accepted steps in {el:.1f}s"}
 
 
 def main():
