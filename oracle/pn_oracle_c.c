@@ -61,24 +61,27 @@ static void precond(const iwp_t* w, double dt, double* p, double* pinv) {
   for (int i = w->n - 1; i >= 0; --i) { p[i] = pw / w->fact[i]; pinv[i] = w->fact[i] / pw; pw *= adt; }
 }
 
-/* Householder QR of the row-major m x n matrix A (m >= n), in place; afterwards the upper triangle of the first
- * n rows holds R (no sign normalisation), the rest is garbage. */
-static void qr_r_inplace(double* A, int m, int n) {
+/* Householder LQ of the row-major n x m matrix A (m >= n), in place: afterwards the lower triangle of the first
+ * n columns holds L with L L^T = A A^T (no sign normalisation); this is the transpose of the reference's
+ * "R factor of a QR of A^T", laid out so that every inner loop runs over contiguous memory. */
+static void lq_inplace(double* A, int n, int m) {
   for (int c = 0; c < n; ++c) {
+    double* x = A + (size_t)c * m;
     double xx = 0.0;
-    for (int r = c + 1; r < m; ++r) xx += A[(size_t)r * n + c] * A[(size_t)r * n + c];
+    for (int q = c + 1; q < m; ++q) xx += x[q] * x[q];
     if (xx == 0.0) continue;
-    double alpha = A[(size_t)c * n + c];
+    double alpha = x[c];
     double beta = -copysign(sqrt(alpha * alpha + xx), alpha);
     double tau = (beta - alpha) / beta, scale = 1.0 / (alpha - beta);
-    for (int r = c + 1; r < m; ++r) A[(size_t)r * n + c] *= scale;
-    A[(size_t)c * n + c] = beta;
+    for (int q = c + 1; q < m; ++q) x[q] *= scale;
+    x[c] = beta;
     for (int j = c + 1; j < n; ++j) {
-      double dot = A[(size_t)c * n + j];
-      for (int r = c + 1; r < m; ++r) dot += A[(size_t)r * n + c] * A[(size_t)r * n + j];
+      double* y = A + (size_t)j * m;
+      double dot = y[c];
+      for (int q = c + 1; q < m; ++q) dot += y[q] * x[q];
       dot *= tau;
-      A[(size_t)c * n + j] -= dot;
-      for (int r = c + 1; r < m; ++r) A[(size_t)r * n + j] -= dot * A[(size_t)r * n + c];
+      y[c] -= dot;
+      for (int q = c + 1; q < m; ++q) y[q] -= dot * x[q];
     }
   }
 }
@@ -137,54 +140,52 @@ double pnoc_dense_step(const iwp_t* w, int N, const double* mean, const double* 
   /* S1 = F1 F1^T, F1 = H (P chol(Qbar) (x) I): only columns j = 0, 1 of chol(Qbar) reach rows 0, 1 */
   {
     double lq00 = p[0] * w->qs[0][0], lq10 = p[1] * w->qs[1][0], lq11 = p[1] * w->qs[1][1];
-    /* F1^T stacked as (2d x d): [ (lq10 I - lq00 J)^T ; lq11 I ] -> R with S1 = R^T R */
+    /* F1 (d x 2d) = [ lq10 I - lq00 J | lq11 I ] -> C1 lower with S1 = C1 C1^T */
     double* Q1 = Ft;
-    for (int c = 0; c < d; ++c)
-      for (int a = 0; a < d; ++a) {
-        Q1[(size_t)c * d + a] = ((a == c) ? lq10 : 0.0) - lq00 * J[a * d + c];
-        Q1[(size_t)(d + c) * d + a] = (a == c) ? lq11 : 0.0;
+    for (int a = 0; a < d; ++a)
+      for (int c = 0; c < d; ++c) {
+        Q1[(size_t)a * 2 * d + c] = ((a == c) ? lq10 : 0.0) - lq00 * J[a * d + c];
+        Q1[(size_t)a * 2 * d + d + c] = (a == c) ? lq11 : 0.0;
       }
     for (int a = 0; a < d; ++a) {
       double s = 0.0;
-      for (int c = 0; c < 2 * d; ++c) s += Q1[(size_t)c * d + a] * Q1[(size_t)c * d + a];
+      for (int c = 0; c < 2 * d; ++c) s += Q1[(size_t)a * 2 * d + c] * Q1[(size_t)a * 2 * d + c];
       err[a] = sqrt(s);
     }
-    qr_r_inplace(Q1, 2 * d, d);
-    /* white = R^-T z */
+    lq_inplace(Q1, d, 2 * d);
+    /* white = C1^-1 z */
     for (int a = 0; a < d; ++a) {
       double acc = z[a];
-      for (int k = 0; k < a; ++k) acc -= Q1[(size_t)k * d + a] * tmp[k];
-      tmp[a] = acc / Q1[(size_t)a * d + a];
+      for (int k = 0; k < a; ++k) acc -= Q1[(size_t)a * 2 * d + k] * tmp[k];
+      tmp[a] = acc / Q1[(size_t)a * 2 * d + a];
     }
   }
   double ww = 0.0;
   for (int a = 0; a < d; ++a) ww += tmp[a] * tmp[a];
   const double sigma = sqrt(ww / d);
   for (int a = 0; a < d; ++a) err[a] *= dt * sigma;
-  /* time update: R = qr_r([ (A L~)^T ; sigma chol(Qbar)^T (x) I ]) in preconditioned coordinates */
-  for (int r = 0; r < D; ++r) {       /* column r of (A L~): row (i,q) */
+  /* time update: L^- = lq([ A L~ | sigma chol(Qbar) (x) I ]) in preconditioned coordinates
+   * (= transpose of the reference's qr_r of the stacked transposes) */
+  for (int r = 0; r < D; ++r) {
     const int i = r / d, q = r % d;
+    double* row = stack + (size_t)r * 2 * D;
     for (int c = 0; c < D; ++c) {
       double acc = 0.0;
       for (int k = i; k < n; ++k) acc += w->a[i][k] * pinv[k] * L[(size_t)(k * d + q) * D + c];
-      stack[(size_t)c * D + r] = acc;  /* transposed */
+      row[c] = acc;
+      const int ic = c / d, qc = c % d;
+      row[D + c] = (q == qc && ic <= i) ? sigma * w->qs[i][ic] : 0.0;
     }
   }
+  lq_inplace(stack, D, 2 * D);
   for (int r = 0; r < D; ++r)
-    for (int c = 0; c < D; ++c) {
-      const int ir = r / d, qr = r % d, ic = c / d, qc = c % d;
-      stack[(size_t)(D + r) * D + c] = (qr == qc && ir <= ic) ? sigma * w->qs[ic][ir] : 0.0;  /* (qs (x) I)^T */
-    }
-  qr_r_inplace(stack, 2 * D, D);
-  for (int r = 0; r < D; ++r)
-    for (int c = 0; c < D; ++c) Lm[(size_t)r * D + c] = (c <= r) ? p[r / d] * stack[(size_t)c * D + r] : 0.0;
+    for (int c = 0; c < D; ++c) Lm[(size_t)r * D + c] = (c <= r) ? p[r / d] * stack[(size_t)r * 2 * D + c] : 0.0;
   /* correction: F = H L^-, S^(T/2) = qr_r(F^T), K = L^- F^T S^-1, m = m^- - K z, L = L^- - K F */
   for (int a = 0; a < d; ++a)
     for (int c = 0; c < D; ++c) {
       double acc = Lm[(size_t)(d + a) * D + c];
       for (int q = 0; q < d; ++q) acc -= J[a * d + q] * Lm[(size_t)q * D + c];
       F[(size_t)a * D + c] = acc;
-      Ft[(size_t)c * d + a] = acc;
     }
   /* cross = L^- F^T  (D x d) */
   for (int r = 0; r < D; ++r)
@@ -193,18 +194,19 @@ double pnoc_dense_step(const iwp_t* w, int N, const double* mean, const double* 
       for (int c = 0; c <= r; ++c) acc += Lm[(size_t)r * D + c] * F[(size_t)a * D + c];
       K[(size_t)r * d + a] = acc;
     }
-  qr_r_inplace(Ft, D, d);  /* R_s (d x d upper) in the first d rows */
-  for (int r = 0; r < D; ++r) {  /* K <- cross R_s^-1 R_s^-T */
+  memcpy(Ft, F, sizeof(double) * (size_t)d * D);
+  lq_inplace(Ft, d, D);  /* C_s (d x d lower, leading dimension D): S = C_s C_s^T */
+  for (int r = 0; r < D; ++r) {  /* K <- cross C_s^-T C_s^-1 */
     double* row = K + (size_t)r * d;
     for (int a = 0; a < d; ++a) {
       double acc = row[a];
-      for (int k = 0; k < a; ++k) acc -= row[k] * Ft[(size_t)k * d + a];
-      row[a] = acc / Ft[(size_t)a * d + a];
+      for (int k = 0; k < a; ++k) acc -= row[k] * Ft[(size_t)a * D + k];
+      row[a] = acc / Ft[(size_t)a * D + a];
     }
     for (int a = d - 1; a >= 0; --a) {
       double acc = row[a];
-      for (int k = a + 1; k < d; ++k) acc -= row[k] * Ft[(size_t)a * d + k];
-      row[a] = acc / Ft[(size_t)a * d + a];
+      for (int k = a + 1; k < d; ++k) acc -= row[k] * Ft[(size_t)k * D + a];
+      row[a] = acc / Ft[(size_t)a * D + a];
     }
   }
   for (int r = 0; r < D; ++r) {
