@@ -430,6 +430,116 @@ static int run_interp(pnode_batch* h, const double* t, const int32_t* slot, bool
 int pnode_interpolate(pnode_batch* h, const double* t, const int32_t* slot) { return run_interp(h, t, slot, false); }
 int pnode_checkpoint_at_step(pnode_batch* h, const int32_t* slot) { return run_interp(h, nullptr, slot, true); }
 
+int pnode_solve_adaptive_save_at(pnode_batch* h, const double* save_at, int32_t num_save, int32_t per_traj,
+                                 const double* dt0, const pnode_control* ctrl, double nz, int64_t max_attempts,
+                                 int64_t* num_steps_out, int64_t* num_attempts_out, uint8_t* failed_out) {
+  if (!h || !save_at || !dt0 || !ctrl || !num_steps_out || !num_attempts_out || !failed_out)
+    return fail(PNODE_EINVAL, "null argument");
+  if (!h->initialised) return fail(PNODE_ESTATE, "set_initial has not been called");
+  const size_t B = h->cfg.batch;
+  const int K = num_save - 1;
+  if (K < 1 || K > h->cfg.num_checkpoints) return fail(PNODE_EINVAL, "num_save - 1 must be in 1..num_checkpoints");
+  auto sa = [&](size_t b, int i) { return per_traj ? save_at[b * num_save + i] : save_at[i]; };
+  for (size_t b = 0; b < B; ++b) {
+    for (int i = 1; i < num_save; ++i)
+      if (!(sa(b, i) > sa(b, i - 1))) return fail(PNODE_EINVAL, "save_at must be strictly increasing");
+    if (!(dt0[b] > 0.0)) return fail(PNODE_EINVAL, "dt0 must be positive");
+  }
+  const double rate = double(h->cfg.nu + 1);
+  const double n1 = ctrl->power_integral_unscaled / rate, n2 = ctrl->power_proportional_unscaled / rate;
+  // factor = safety * (1/e)^n1 * (e_prev/e)^n2 = safety * exp(n2*log(e_prev) - (n1+n2)*log(e)); log(e_prev) is cached
+  std::vector<double> dt(dt0, dt0 + B), log_prev(B, 0.0), err(B, 0.0), dt_used(B, 1.0), tq(B, 0.0);
+  std::vector<int32_t> cursor(B, 1), slot(B, -1);
+  std::vector<uint8_t> active(B, 0), accept(B, 0);
+  std::vector<int64_t> attempts(B, 0);
+  for (size_t b = 0; b < B; ++b) {
+    failed_out[b] = 0;
+    for (int i = 0; i < num_save; ++i) num_steps_out[b * num_save + i] = 0;
+  }
+  int64_t rounds = 0;
+  for (;;) {
+    // ---- checkpoints reached by STEP_FROM (possibly several per accepted step)
+    for (;;) {
+      bool any_over = false, any_corner = false;
+      for (size_t b = 0; b < B; ++b) {
+        slot[b] = -1;
+        if (cursor[b] > K || failed_out[b]) continue;
+        const double nxt = sa(b, cursor[b]);
+        if (h->t_sf[b] + nz >= nxt && h->t_sf[b] > nxt + nz) {
+          slot[b] = cursor[b] - 1;
+          tq[b] = nxt;
+          any_over = true;
+        }
+      }
+      if (any_over) {
+        int rc = pnode_interpolate(h, tq.data(), slot.data());
+        if (rc != PNODE_OK) return rc;
+        for (size_t b = 0; b < B; ++b)
+          if (slot[b] >= 0) {
+            num_steps_out[b * num_save + cursor[b]] = h->steps[b];
+            cursor[b] += 1;
+          }
+      }
+      for (size_t b = 0; b < B; ++b) {
+        slot[b] = -1;
+        if (cursor[b] > K || failed_out[b]) continue;
+        const double nxt = sa(b, cursor[b]);
+        if (h->t_sf[b] + nz >= nxt && !(h->t_sf[b] > nxt + nz)) {
+          slot[b] = cursor[b] - 1;
+          any_corner = true;
+        }
+      }
+      if (any_corner) {
+        int rc = pnode_checkpoint_at_step(h, slot.data());
+        if (rc != PNODE_OK) return rc;
+        for (size_t b = 0; b < B; ++b)
+          if (slot[b] >= 0) {
+            num_steps_out[b * num_save + cursor[b]] = h->steps[b];
+            cursor[b] += 1;
+          }
+      }
+      if (!any_over && !any_corner) break;
+    }
+    // ---- one batched attempt for every trajectory that still has a checkpoint ahead
+    bool any = false;
+    for (size_t b = 0; b < B; ++b) {
+      active[b] = (cursor[b] <= K && !failed_out[b]) ? 1 : 0;
+      double d = dt[b];
+      if (active[b] && ctrl->clip) d = std::fmin(d, sa(b, cursor[b]) - h->t_sf[b]);
+      dt_used[b] = active[b] ? d : 1.0;
+      any = any || active[b];
+    }
+    if (!any) break;
+    if (max_attempts > 0 && rounds >= max_attempts) return fail(PNODE_ESTATE, "max_attempts reached");
+    ++rounds;
+    int rc = pnode_attempt_step(h, dt_used.data(), active.data(), err.data());
+    if (rc != PNODE_OK) return rc;
+    for (size_t b = 0; b < B; ++b) {
+      accept[b] = 0;
+      if (!active[b]) continue;
+      attempts[b] += 1;
+      const double e = err[b];
+      if (e != e) {  // NaN error estimate: the reference's controller turns dt into NaN; stop the trajectory
+        failed_out[b] = 1;
+        accept[b] = 1;  // ... after leaving the `while error_norm > 1` loop, i.e. with the NaN state accepted
+        continue;
+      }
+      const double le = std::log(e);
+      const double raw = ctrl->safety * std::exp(n2 * log_prev[b] - (n1 + n2) * le);
+      const double factor = std::fmax(ctrl->factor_min, std::fmin(raw, ctrl->factor_max));
+      if (e <= 1.0) log_prev[b] = le;
+      dt[b] = factor * dt_used[b];
+      accept[b] = !(e > 1.0);
+    }
+    rc = pnode_commit(h, accept.data());
+    if (rc != PNODE_OK) return rc;
+    for (size_t b = 0; b < B; ++b)
+      if (active[b] && !(std::isfinite(dt[b]) && std::isfinite(h->t_sf[b]) && dt[b] > 0.0)) failed_out[b] = 1;
+  }
+  for (size_t b = 0; b < B; ++b) num_attempts_out[b] = attempts[b];
+  return PNODE_OK;
+}
+
 int pnode_solve_fixed_grid(pnode_batch* h, const double* grid, int32_t G, int32_t per_traj, double* u_out) {
   if (!h || !grid || !u_out || G < 1) return fail(PNODE_EINVAL, "bad argument");
   if (!h->initialised) return fail(PNODE_ESTATE, "set_initial has not been called");

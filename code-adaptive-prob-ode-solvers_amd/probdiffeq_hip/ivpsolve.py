@@ -171,30 +171,9 @@ def _finish(sol_means, init, kind, batch, t, num_steps, loop, squeeze):
     return Solution(t, u, post, out_scale, num_steps, loop.attempts.copy())
 
 
-def solve_adaptive_save_at(vector_field, initial_condition: InitialCondition, save_at, adaptive_solver: AdaptiveSolver,
-                           dt0, *, device=None) -> Solution:
-    """Adaptive solve that stores the solution at `save_at` only (fixed memory, O(len(save_at))).
-
-    save_at: (K+1,) shared or (B, K+1) per trajectory; save_at[..., 0] is the initial time. Steps are
-    not clipped (unless control.clip): an accepted step that oversteps a checkpoint is interpolated.
-    With strategy_fixedpoint, `Solution.u` holds the smoothed means (backward pass over the stored
-    checkpoint transitions), as probdiffeq's solution object does.
-    """
-    solver = adaptive_solver.solver
-    if not solver.strategy.is_suitable_for_save_at:
-        warnings.warn("strategy is not suitable for save_at", stacklevel=2)
-    init = initial_condition
-    B, n, d = init.tcoeffs.shape
-    sa = np.asarray(save_at, dtype=np.float64)
-    sa_b = np.ascontiguousarray(np.broadcast_to(sa, (B, sa.shape[-1])))
-    K = sa_b.shape[1] - 1
-    if K < 1 or np.any(np.diff(sa_b, axis=1) <= 0):
-        raise ValueError("save_at must be strictly increasing with at least two points")
-    batch = _make_batch(vector_field, init, solver, K, device)
-    batch.set_initial(init.tcoeffs, sa_b[:, 0], init.output_scale)
-    batch.set_tolerances(adaptive_solver.atol, adaptive_solver.rtol)
-    loop = _AdaptiveLoop(batch, adaptive_solver, sa_b[:, 0], dt0)
-    nz = adaptive_solver.numerical_zero
+def _python_save_at_loop(batch, loop, sa_b, K, nz):
+    """The driver loop in Python/NumPy (reference implementation of the native pnode_solve_adaptive_save_at)."""
+    B = batch.B
     cursor = np.ones(B, dtype=np.int64)
     num_steps = np.zeros((B, K + 1), dtype=np.int64)
     rows = np.arange(B)
@@ -218,6 +197,41 @@ def solve_adaptive_save_at(vector_field, initial_condition: InitialCondition, sa
             break
         t_next = sa_b[rows, np.minimum(cursor, K)]
         loop.attempt(active, t1=t_next)
+    return cursor, num_steps
+
+
+def solve_adaptive_save_at(vector_field, initial_condition: InitialCondition, save_at, adaptive_solver: AdaptiveSolver,
+                           dt0, *, device=None, python_controller=False) -> Solution:
+    """Adaptive solve that stores the solution at `save_at` only (fixed memory, O(len(save_at))).
+
+    save_at: (K+1,) shared or (B, K+1) per trajectory; save_at[..., 0] is the initial time. Steps are
+    not clipped (unless control.clip): an accepted step that oversteps a checkpoint is interpolated.
+    With strategy_fixedpoint, `Solution.u` holds the smoothed means (backward pass over the stored
+    checkpoint transitions), as probdiffeq's solution object does.
+    """
+    solver = adaptive_solver.solver
+    if not solver.strategy.is_suitable_for_save_at:
+        warnings.warn("strategy is not suitable for save_at", stacklevel=2)
+    init = initial_condition
+    B, n, d = init.tcoeffs.shape
+    sa = np.asarray(save_at, dtype=np.float64)
+    sa_b = np.ascontiguousarray(np.broadcast_to(sa, (B, sa.shape[-1])))
+    K = sa_b.shape[1] - 1
+    if K < 1 or np.any(np.diff(sa_b, axis=1) <= 0):
+        raise ValueError("save_at must be strictly increasing with at least two points")
+    batch = _make_batch(vector_field, init, solver, K, device)
+    batch.set_initial(init.tcoeffs, sa_b[:, 0], init.output_scale)
+    batch.set_tolerances(adaptive_solver.atol, adaptive_solver.rtol)
+    loop = _AdaptiveLoop(batch, adaptive_solver, sa_b[:, 0], dt0)
+    if python_controller:
+        cursor, num_steps = _python_save_at_loop(batch, loop, sa_b, K, adaptive_solver.numerical_zero)
+    else:
+        # native driver: same controller arithmetic and call sequence, in C++ inside libpnode_hip.so
+        num_steps, attempts, failed = batch.solve_adaptive_save_at(sa if sa.ndim == 1 else sa_b, loop.dt, adaptive_solver.control,
+                                                                   adaptive_solver.numerical_zero)
+        loop.attempts, loop.failed = attempts, failed
+        cursor = np.where(failed, 1 + np.argmax(np.concatenate([num_steps[:, 1:] == 0, np.ones((B, 1), bool)], axis=1), axis=1),
+                          K + 1)
     if solver.strategy.kind == "fixedpoint":
         means = batch.smooth_checkpoint_means(np.minimum(cursor - 1, K))
         # the smoothed value at t0 equals the initial mean up to rounding; keep the backward-pass value

@@ -118,6 +118,27 @@ int pnode_interpolate(pnode_batch* h, const double* t, const int32_t* slot);
 /* Same, for the case STEP_FROM.t == save_at point (no interpolation needed). */
 int pnode_checkpoint_at_step(pnode_batch* h, const int32_t* slot);
 
+/* ivpsolve.control_proportional_integral(...) parameters (defaults: 0.95, 0.2, 10, 0.3, 0.4, no clipping). */
+typedef struct pnode_control {
+  double safety, factor_min, factor_max, power_integral_unscaled, power_proportional_unscaled;
+  int32_t clip;      /* 1: clip dt to the next save_at point instead of overstepping + interpolating */
+  int32_t reserved;
+} pnode_control;
+
+/* The whole adaptive driver loop of ivpsolve.solve_adaptive_save_at (ivpsolvers.py:71-77, run.py:122-129) in
+ * native host code: per batched attempt one pnode_attempt_step, the PI controller + accept/reject for every
+ * trajectory (sequential host arithmetic, as in the reference), pnode_commit, and checkpoint interpolation
+ * whenever an accepted step reaches the next save_at point. Exactly the sequence the Python driver issues,
+ * without the interpreter between launches.
+ * save_at: [num_save] shared (per_trajectory = 0) or [B][num_save]; save_at[..., 0] must equal the time given to
+ * pnode_set_initial and num_save - 1 <= num_checkpoints. dt0: [B]. error_contraction_rate = nu + 1.
+ * num_steps_out: [B][num_save] accepted steps at each save_at point; num_attempts_out: [B];
+ * failed_out: [B] (1: a non-finite step size or time stopped the trajectory). max_attempts <= 0: unlimited. */
+int pnode_solve_adaptive_save_at(pnode_batch* h, const double* save_at, int32_t num_save, int32_t per_trajectory,
+                                 const double* dt0, const pnode_control* control, double numerical_zero,
+                                 int64_t max_attempts, int64_t* num_steps_out, int64_t* num_attempts_out,
+                                 uint8_t* failed_out);
+
 /* Device-side replay of a prescribed grid without controller: ivpsolve.solve_fixed_grid
  * (vdp.py:88-103). grid: [G] shared by all trajectories (grid_per_trajectory = 0) or [B][G].
  * u_out: [B][G][d] zeroth-derivative means (u_out[:,0] = initial value). All launches are enqueued

@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Throughput of the BASELINE.json configurations C1-C4 on one GPU, whole adaptive solves.
+
+Prints one JSON line per configuration: accepted steps/s (sum over the batch / wall time incl. the host
+controller), attempted steps/s, batched attempts, and a truth check against scipy where cheap.
+Not the headline bench (that is bench.py); this is the coverage table for DESIGN.md / profiles/.
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "code-adaptive-prob-ode-solvers_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+
+from odecheckpts import ivps  # noqa: E402
+from probdiffeq_hip import ivpsolve, ivpsolvers, taylor  # noqa: E402
+from probdiffeq_hip.impl import impl  # noqa: E402
+
+
+def run(name, vf, u0s, t0, t1, *, model, corr, strategy, nu, atol, rtol, dt0, num_save=5, truth=None):
+    import warnings
+
+    warnings.simplefilter("ignore")
+    d = vf.d
+    impl.select(model, ode_shape=(d,))
+    correction = (ivpsolvers.correction_ts1 if corr == "ts1" else ivpsolvers.correction_ts0)(ode_order=vf.ode_order)
+    strat = (ivpsolvers.strategy_fixedpoint if strategy == "fixedpoint" else ivpsolvers.strategy_filter)(
+        ivpsolvers.prior_ibm(nu), correction)
+    solver = ivpsolvers.solver_dynamic(strat)
+    tcs = taylor.odejet_padded_scan(vf, u0s, num=nu + 1 - vf.ode_order)
+    init = solver.initial_condition(tcs, 1.0)
+    save_at = np.linspace(t0, t1, num_save)
+    asolver = ivpsolve.adaptive(solver, atol=atol, rtol=rtol)
+    # warm-up (first launch compiles nothing but pages code in)
+    ivpsolve.solve_adaptive_save_at(vf, init, save_at=np.linspace(t0, t0 + 1e-3 * (t1 - t0), 2), dt0=dt0, adaptive_solver=asolver)
+    tic = time.perf_counter()
+    sol = ivpsolve.solve_adaptive_save_at(vf, init, save_at=save_at, dt0=dt0, adaptive_solver=asolver)
+    el = time.perf_counter() - tic
+    acc = int(np.sum(sol.num_steps[..., -1]))
+    att = int(np.sum(sol.num_attempts))
+    B = init.tcoeffs.shape[0]
+    out = {"config": name, "batch": B, "d": d, "nu": nu, "model": model, "correction": corr, "strategy": strategy,
+           "accepted_steps": acc, "attempted_steps": att, "seconds": round(el, 4),
+           "accepted_steps_per_s": acc / el, "finite": bool(np.all(np.isfinite(sol.u)))}
+    if truth is not None:
+        out["max_abs_err_vs_truth_at_t1"] = float(np.max(np.abs(np.atleast_2d(sol.u)[..., -1, :] - truth)))
+    print(json.dumps(out), flush=True)
+
+
+def main():
+    from scipy.integrate import solve_ivp
+
+    # C1: Van der Pol mu=1, d=2, nu=3, EKF0 isotropic, single trajectory
+    vf, u0, (t0, t1), _ = ivps.van_der_pol_first_order(1.0)
+    tr = solve_ivp(lambda t, y: vf(y), (t0, t1), u0[0], rtol=1e-12, atol=1e-12, method="DOP853").y[:, -1]
+    run("C1 vdp mu=1 (single)", vf, [u0[0]], t0, t1, model="isotropic", corr="ts0", strategy="filter", nu=3,
+        atol=1e-6, rtol=1e-6, dt0=0.1, truth=tr)
+    # C2: stiff Van der Pol mu=1e3 (2nd order, d=1), nu=4, EKF1 dense, tolerance sweep B=256
+    vf, u0, (t0, t1) = ivps.van_der_pol(1e3)
+    B = 256
+    tols = 10.0 ** np.linspace(-2, -8, B)
+    run("C2 vdp mu=1e3 EKF1 sweep", vf, [np.tile(u0[0], (B, 1)), np.tile(u0[1], (B, 1))], t0, t1, model="dense", corr="ts1",
+        strategy="filter", nu=4, atol=tols, rtol=tols, dt0=0.01)
+    # C3a: rigid body d=3, t in [0, 50], nu = 2..5 isotropic fixedpoint, 256 tolerances each
+    vf, u0, (t0, t1), _ = ivps.rigid_body(time_span=(0.0, 50.0))
+    tr = solve_ivp(lambda t, y: vf(y), (t0, t1), u0[0], rtol=1e-13, atol=1e-13, method="LSODA").y[:, -1]
+    B = 256
+    rt = 10.0 ** np.linspace(-1, -7, B)
+    for nu in (2, 3, 4, 5):
+        run(f"C3 rigid body nu={nu} sweep", vf, [np.tile(u0[0], (B, 1))], t0, t1, model="isotropic", corr="ts0",
+            strategy="fixedpoint", nu=nu, atol=1e-3 * rt, rtol=rt, dt0=0.1)
+    # C3b: Pleiades 2nd order d=14
+    vf, u0, (t0, t1) = ivps.pleiades_2nd()
+    for nu in (3, 5):
+        run(f"C3 pleiades nu={nu} sweep", vf, [np.tile(u0[0], (B, 1)), np.tile(u0[1], (B, 1))], t0, t1, model="isotropic",
+            corr="ts0", strategy="fixedpoint", nu=nu, atol=1e-3 * rt, rtol=rt, dt0=0.01)
+    # C4: Brusselator N=32, B=1024: isotropic EKF0 (the model the reference uses) and dense EKF1 (headline)
+    import bench
+
+    vf, tcs = bench.problem_batch(1024)
+    y0 = tcs[0]
+    run("C4 brusselator iso EKF0 nu=3", vf, [y0], 0.0, 10.0, model="isotropic", corr="ts0", strategy="filter", nu=3,
+        atol=1e-6, rtol=1e-6, dt0=0.01)
+    run("C4 brusselator dense EKF1 nu=3", vf, [y0], 0.0, 10.0, model="dense", corr="ts1", strategy="filter", nu=3,
+        atol=1e-6, rtol=1e-6, dt0=0.01)
+
+
+if __name__ == "__main__":
+    sys.path.insert(0, ROOT)
+    main()
