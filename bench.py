@@ -162,9 +162,9 @@ def main():
     batch = ivpsolve._make_batch(vf, init, solver, 1, device=local)
     batch.set_initial(init.tcoeffs, np.zeros(B), init.output_scale)
     batch.set_tolerances(TOL, TOL)
-    if dense:
-        batch.set_phase_timing(True)
+    batch.set_phase_timing(True)  # HIP events around the step (and between the dense kernels)
     loop = ivpsolve._AdaptiveLoop(batch, asolver, np.zeros(B), DT0)
+    loop.time_device = True
     active = np.ones(B, dtype=bool)
 
     def barrier():

@@ -100,6 +100,9 @@ struct pnode_batch {
   InterpArg* dIargs = nullptr;
   int32_t* dFilled = nullptr;
   double *dAtol = nullptr, *dRtol = nullptr, *dPrm = nullptr, *dErr = nullptr;
+  StepArg* zArgs = nullptr;     // device view of hArgs (zero-copy: kernels read the per-step arguments over PCIe)
+  double* zErr = nullptr;       // device view of hErr  (kernels write the error norms straight to pinned host memory)
+  bool step_timing = false;
   StepArg* hArgs = nullptr;     // pinned
   InterpArg* hIargs = nullptr;  // pinned
   double* hErr = nullptr;       // pinned
@@ -203,6 +206,8 @@ int pnode_create(const pnode_config* cfg, pnode_batch** out) {
   HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->hArgs), B * sizeof(StepArg)));
   HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->hIargs), B * sizeof(InterpArg)));
   HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->hErr), B * sizeof(double)));
+  HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->zArgs), h->hArgs, 0));
+  HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->zErr), h->hErr, 0));
 
   ALLOC(h->dK, 1);
   ALLOC(h->dArgs, B);
@@ -238,7 +243,7 @@ int pnode_create(const pnode_config* cfg, pnode_batch** out) {
       ALLOC(v.ck_xi, B * Kc * n * d);
       ALLOC(v.ck_Lam, B * Kc * n * n);
     }
-    v.atol = h->dAtol; v.rtol = h->dRtol; v.prm = nprm ? h->dPrm : nullptr; v.errnorm = h->dErr;
+    v.atol = h->dAtol; v.rtol = h->dRtol; v.prm = nprm ? h->dPrm : nullptr; v.errnorm = h->zErr;
   } else {
     DenseView& v = h->dn;
     v.B = int(B); v.d = d; v.k = k; v.n = int(n); v.D = int(D); v.K = int(Kc);
@@ -260,7 +265,7 @@ int pnode_create(const pnode_config* cfg, pnode_batch** out) {
     ALLOC(v.X, B * D * d);
     ALLOC(v.S, B * d * d);
     ALLOC(v.sig_new, B);
-    v.atol = h->dAtol; v.rtol = h->dRtol; v.prm = nprm ? h->dPrm : nullptr; v.errnorm = h->dErr;
+    v.atol = h->dAtol; v.rtol = h->dRtol; v.prm = nprm ? h->dPrm : nullptr; v.errnorm = h->zErr;
   }
   h->t_sf.assign(B, 0.0);
   h->t_if.assign(B, 0.0);
@@ -351,12 +356,12 @@ int pnode_attempt_step(pnode_batch* h, const double* dt, const uint8_t* active, 
     h->pending[b] = active[b] ? 1 : 0;
     h->dt_pending[b] = dt[b];
   }
-  HIP_TRY(hipMemcpyAsync(h->dArgs, h->hArgs, B * sizeof(StepArg), hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(hipEventRecord(h->ev0, h->stream));
-  enqueue_step(h, h->dArgs);
-  HIP_TRY(hipEventRecord(h->ev1, h->stream));
+  // zero-copy hand-over: the kernels read StepArg[B] from and write err_norm[B] to pinned host memory, so a step
+  // costs the launches plus one stream synchronisation (no hipMemcpy calls on the critical path)
+  if (h->step_timing) HIP_TRY(hipEventRecord(h->ev0, h->stream));
+  enqueue_step(h, h->zArgs);
+  if (h->step_timing) HIP_TRY(hipEventRecord(h->ev1, h->stream));
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(h->hErr, h->dErr, B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   for (size_t b = 0; b < B; ++b)
     if (active[b]) err_norm_out[b] = h->hErr[b];
@@ -697,6 +702,7 @@ int pnode_smooth_checkpoint_means(pnode_batch* h, const int32_t* num_filled, dou
 
 int pnode_last_step_ms(pnode_batch* h, float* ms_out) {
   if (!h || !ms_out) return fail(PNODE_EINVAL, "null argument");
+  if (!h->step_timing) return fail(PNODE_ESTATE, "step timing is off: call pnode_set_phase_timing(h, 1) first");
   HIP_TRY(hipEventElapsedTime(ms_out, h->ev0, h->ev1));
   return PNODE_OK;
 }
@@ -719,6 +725,7 @@ int pnode_debug_read_scratch(pnode_batch* h, int32_t b, int32_t offset_words, in
 int pnode_set_phase_timing(pnode_batch* h, int32_t enabled) {
   if (!h) return fail(PNODE_EINVAL, "null handle");
   h->phase_timing = enabled != 0;
+  h->step_timing = enabled != 0;
   return PNODE_OK;
 }
 

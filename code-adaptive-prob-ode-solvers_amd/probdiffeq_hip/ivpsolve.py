@@ -135,6 +135,7 @@ class _AdaptiveLoop:
         self.attempts = np.zeros(B, dtype=np.int64)
         self.failed = np.zeros(B, dtype=bool)
         self._err = np.zeros(B)
+        self.time_device = False
         self.device_ms = 0.0
         self.num_launches = 0
 
@@ -145,7 +146,8 @@ class _AdaptiveLoop:
             dt = np.where(active, np.minimum(dt, t1 - self.t), dt)
         dt_used = np.where(active, dt, 1.0)
         err = self.batch.attempt_step(dt_used, active, self._err)
-        self.device_ms += self.batch.last_step_ms()
+        if self.time_device:
+            self.device_ms += self.batch.last_step_ms()
         self.num_launches += 1
         self.attempts += active
         new_dt, new_prev = self.ctrl.apply(dt_used, self.err_prev, err, self.rate)

@@ -162,7 +162,7 @@ int pnode_read_checkpoint_means(pnode_batch* h, double* out);
 int pnode_smooth_checkpoint_means(pnode_batch* h, const int32_t* num_filled, double* out);
 
 /* Timing of the device work of the most recent attempt_step (HIP events on the handle's stream),
- * in milliseconds; used by bench.py for the roofline line. */
+ * in milliseconds; used by bench.py for the roofline line. Needs pnode_set_phase_timing(h, 1). */
 int pnode_last_step_ms(pnode_batch* h, float* ms_out);
 /* Diagnostics (dense): raw 64-bit words of a trajectory's scratch area (in-kernel cycle stamps of
  * timing-only builds, PNODE_ABLATE & 128). Never part of a result. */
@@ -170,7 +170,7 @@ int pnode_debug_read_scratch(pnode_batch* h, int32_t b, int32_t offset_words, in
 /* Dense model only: 1 forces the generic (non-MFMA) kernels even where the MFMA fast path applies
  * (A/B testing of the two device paths; both are HIP, neither is a CPU fallback). */
 int pnode_set_generic_path(pnode_batch* h, int32_t enabled);
-/* Dense model only: record HIP events between the kernels of a step (on the handle's stream) and
+/* Enables HIP-event timing of attempt_step (all models). Dense model: also record HIP events between the kernels of a step (on the handle's stream) and
  * read the durations of the last attempt, ms_out[4] = {begin, lq_input, lq, correct}. */
 int pnode_set_phase_timing(pnode_batch* h, int32_t enabled);
 int pnode_last_phase_ms(pnode_batch* h, float* ms_out);
