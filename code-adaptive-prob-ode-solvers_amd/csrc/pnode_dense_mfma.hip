@@ -9,7 +9,8 @@
 //      lane (r = lane & 15, g = lane >> 4) holds X[s] = M[row0 + r][4 s + g],  s = 0 .. D/4 - 1,
 // which is at once the B operand of  G^T = Vx X^T  and the C/D fragment of the transposed update
 // X^T -= Vx^T W^T, so a strip is read once and written once per panel with no LDS staging.
-// The measurement update (projector form) uses the same strip scheme and the fact that L^- is lower
+// Pass 0 reads the state factor L directly (Mt is formed on the fly). The measurement update (projector form)
+// uses the same strip scheme and the fact that L^- is lower
 // triangular: F = H L^- has only 2d non-zero columns, so Y = L^- W^T and L = L^- - Y W touch D x 2d.
 //
 // Reference anchors: strategy_filter + correction_ts1 + solver_dynamic
@@ -43,172 +44,7 @@ __device__ __forceinline__ void precond_rt(int n, double dt, const IwpConst& K, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Blocked LQ:  [T0 | Mt]  ->  T (lower triangular, written to v.R), Mt destroyed.
-// DT = D / 16. One workgroup of 256 threads per trajectory.
-// ---------------------------------------------------------------------------------------------
-template <int DT>
-__global__ __launch_bounds__(256) void dense_lq_mfma_kernel(DenseView v, const StepArg* __restrict__ args,
-                                                            const IwpConst* __restrict__ Kc) {
-  constexpr int D = 16 * DT;
-  constexpr int LDV = D + 2;  // LDS row stride (doubles): conflict-free MFMA operand reads
-  constexpr int NS = D / 4;   // k-steps over the full width
-  __shared__ double Vx[kNB * LDV];
-  __shared__ double Tpp[kNB * kNB];
-  __shared__ double Tf[kNB * kNB];
-  __shared__ double Gs[4 * kNB * kNB];
-  __shared__ double tau[kNB];
-
-  const int b = blockIdx.x;
-  if (!args[b].active) return;
-  const IwpConst& K = *Kc;
-  const int d = v.d;
-  const double sigma = v.sig_new[b];
-  double* __restrict__ Mt = v.M + size_t(b) * D * D;
-  double* __restrict__ T = v.R + size_t(b) * D * D;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int r = lane & 15, g = lane >> 4;
-  const int rr = tid >> 4, ch = tid & 15;  // panel factorisation mapping: (row, interleaved column class)
-
-  for (int p = 0; p < DT; ++p) {
-    const int c0 = kNB * p;
-    const int iblk = c0 / d;  // the whole panel lies in derivative block iblk (d % 16 == 0)
-    const double t0diag = sigma * K.qsT[iblk][iblk];
-    // ---- load the panel rows of Mt, initialise the diagonal block of T0
-    for (int idx = tid; idx < kNB * D; idx += 256) {
-      const int i = idx / D, c = idx % D;
-      Vx[i * LDV + c] = Mt[size_t(c0 + i) * D + c];
-    }
-    Tpp[tid] = ((tid >> 4) == (tid & 15)) ? t0diag : 0.0;
-    __syncthreads();
-    // ---- unblocked row-Householder on the panel
-    for (int c = 0; c < ((v.ablate & 1) ? 0 : kNB); ++c) {
-      if (rr == c) {
-        double part = 0.0;
-#pragma unroll
-        for (int i = 0; i < DT; ++i) {
-          const double x = Vx[c * LDV + ch + 16 * i];
-          part += x * x;
-        }
-        const double xx = group16_sum(part);
-        const double alpha = Tpp[c * kNB + c];
-        double tauc = 0.0, scale = 0.0, beta = alpha;
-        if (xx != 0.0) {
-          beta = -copysign(sqrt(alpha * alpha + xx), alpha);
-          tauc = (beta - alpha) / beta;
-          scale = 1.0 / (alpha - beta);
-        }
-#pragma unroll
-        for (int i = 0; i < DT; ++i) Vx[c * LDV + ch + 16 * i] *= scale;
-        if (ch == 0) {
-          Tpp[c * kNB + c] = beta;
-          tau[c] = tauc;
-        }
-      }
-      __syncthreads();
-      if (rr > c) {
-        const double tauc = tau[c];
-        if (tauc != 0.0) {
-          double part = 0.0;
-#pragma unroll
-          for (int i = 0; i < DT; ++i) part += Vx[rr * LDV + ch + 16 * i] * Vx[c * LDV + ch + 16 * i];
-          const double dot = group16_sum(part);
-          const double tjc = Tpp[rr * kNB + c];
-          const double w = tauc * (tjc + dot);
-#pragma unroll
-          for (int i = 0; i < DT; ++i) Vx[rr * LDV + ch + 16 * i] -= w * Vx[c * LDV + ch + 16 * i];
-          if (ch == 0) Tpp[rr * kNB + c] = tjc - w;
-        }
-      }
-      __syncthreads();
-    }
-    // ---- final diagonal block of T
-    {
-      const int i = tid >> 4, j = tid & 15;
-      if (j <= i) T[size_t(c0 + i) * D + c0 + j] = Tpp[i * kNB + j];
-    }
-    if (p == DT - 1) break;
-    // ---- Gram of the reflector rows (each wave a quarter of the columns), then the T-factor
-    {
-      double4_t acc = {0.0, 0.0, 0.0, 0.0};
-      constexpr int per = NS / 4;
-#pragma unroll
-      for (int s = 0; s < per; ++s) {
-        const double a = Vx[r * LDV + 4 * (wv * per + s) + g];
-        acc = MFMA64(a, a, acc);
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) Gs[wv * 256 + (g + 4 * q) * kNB + r] = acc[q];
-    }
-    __syncthreads();
-    if (tid < kNB && !(v.ablate & 4)) {
-      // lane i owns row i of Tf (upper triangular, forward product H_0 H_1 ... = I - V^T Tf V)
-      const int i = tid;
-      double row[kNB];
-#pragma unroll
-      for (int j = 0; j < kNB; ++j) row[j] = 0.0;
-#pragma unroll
-      for (int j = 0; j < kNB; ++j) {
-        const double tj = tau[j];
-        double acc = 0.0;
-#pragma unroll
-        for (int m = 0; m < kNB; ++m) {
-          if (m < j) {
-            const double gm = Gs[m * kNB + j] + Gs[256 + m * kNB + j] + Gs[512 + m * kNB + j] + Gs[768 + m * kNB + j];
-            acc += row[m] * gm;
-          }
-        }
-        row[j] = (i == j) ? tj : ((i < j) ? -tj * acc : 0.0);
-      }
-#pragma unroll
-      for (int j = 0; j < kNB; ++j) Tf[i * kNB + j] = row[j];
-    }
-    __syncthreads();
-    // ---- trailing update, one 16-row strip per wave at a time
-    const int nstrips = (v.ablate & 2) ? 0 : DT - 1 - p;
-    for (int st = wv; st < nstrips; st += 4) {
-      const int j0 = c0 + kNB * (st + 1);
-      double* __restrict__ rowp = Mt + size_t(j0 + r) * D + g;
-      double X[NS];
-#pragma unroll
-      for (int s = 0; s < NS; ++s) X[s] = rowp[4 * s];
-      // G^T = T0[J][P]^T + Vx X^T   (T0 couples equal intra-block indices of different blocks)
-      const int jblk = j0 / d;
-      double4_t t0v, acc;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int cc = g + 4 * q;
-        t0v[q] = (((j0 + r) % d) == ((c0 + cc) % d)) ? sigma * K.qsT[iblk][jblk] : 0.0;
-      }
-      acc = t0v;
-#pragma unroll
-      for (int s = 0; s < NS; ++s) acc = MFMA64(Vx[r * LDV + 4 * s + g], X[s], acc);
-      // W^T = Tf^T G^T
-      double4_t w4 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) w4 = MFMA64(Tf[(4 * kk + g) * kNB + r], acc[kk], w4);
-      // T[J][P] = T0 - W
-#pragma unroll
-      for (int q = 0; q < 4; ++q) T[size_t(j0 + r) * D + c0 + g + 4 * q] = t0v[q] - w4[q];
-      // X^T -= Vx^T W^T
-#pragma unroll
-      for (int t = 0; t < DT; ++t) {
-        double4_t c4 = {X[4 * t], X[4 * t + 1], X[4 * t + 2], X[4 * t + 3]};
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) c4 = MFMA64(-Vx[(4 * kk + g) * LDV + 16 * t + r], w4[kk], c4);
-        X[4 * t] = c4[0];
-        X[4 * t + 1] = c4[1];
-        X[4 * t + 2] = c4[2];
-        X[4 * t + 3] = c4[3];
-      }
-#pragma unroll
-      for (int s = 0; s < NS; ++s) rowp[4 * s] = X[s];
-    }
-    __syncthreads();
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Blocked LQ, second generation: 32-row outer blocks (two 16-row panels A, B per pass over the
+// Blocked row-Householder LQ:  [T0 | Mt] -> T (lower triangular, written to v.R); 32-row outer blocks (two 16-row panels A, B per pass over the
 // trailing rows, halving the trailing-matrix traffic), DPP reductions and ONE barrier per panel row.
 // Strip register layout for HBM rows (128 contiguous bytes per lane per 64-column super-tile):
 //      X[16 T + 4 j + q] = M[row0 + r][64 T + 16 g + 4 j + q]
@@ -422,11 +258,6 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
   double* __restrict__ T = v.R + size_t(b) * D * D;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
-  if (v.ablate & 64) {
-    // diagnostics: de-phase the co-resident workgroups of a CU (second dispatch wave starts later)
-    if ((blockIdx.x >> 8) & 1)
-      for (int i = 0; i < (v.ablate >> 8); ++i) __builtin_amdgcn_s_sleep(127);
-  }
   // pass 0 reads the state factor L directly: Mt = (Abar P^-1 (x) I) L is formed on the fly (no separate
   // kernel, no extra HBM round trip); coef[i][k] = Abar[i][k] / p_k
   __shared__ double coef[kMaxN * kMaxN];
@@ -598,160 +429,7 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
 }
 
 // ---------------------------------------------------------------------------------------------
-// Measurement update (ode order 1):  F = H L^-, S = F F^T = C C^T, W = C^-1 F, Y = L^- W^T,
-// m = m^- - Y C^-1 z, L = L^- - Y W, normalised error norm. DT = D/16, DD = d/16.
-// ---------------------------------------------------------------------------------------------
-template <int DT, int DD>
-__global__ __launch_bounds__(256) void dense_correct_mfma_kernel(DenseView v, const StepArg* __restrict__ args,
-                                                                 const IwpConst* __restrict__ Kc) {
-  constexpr int D = 16 * DT, d = 16 * DD, W2 = 2 * d;  // F has W2 non-zero columns
-  constexpr int LDF = W2 + 2, LDS_ = d + 1;
-  extern __shared__ double smem[];
-  double* Fw = smem;              // [d][LDF]   F, then W
-  double* Sm = Fw + d * LDF;      // [d][LDS_]  S, then C
-  double* wz = Sm + d * LDS_;     // [d]
-  double* tv = wz + d;            // [W2]   W^T wz
-  double* red = tv + W2;          // [4]
-  double* p = red + 4;            // [kMaxN]  preconditioner (LDS: indexed dynamically)
-
-  const int b = blockIdx.x;
-  const StepArg arg = args[b];
-  if (!arg.active) return;
-  const IwpConst& K = *Kc;
-  const int n = v.n;
-  const double* __restrict__ T = v.R + size_t(b) * D * D;
-  const double* __restrict__ Jg = v.J + size_t(b) * d * d;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  if (tid == 0) {
-    double pl[kMaxN], pil[kMaxN];
-    precond_rt(n, arg.dt, K, pl, pil);
-    for (int i = 0; i < n; ++i) p[i] = pl[i];
-  }
-  __syncthreads();
-  const int r = lane & 15, g = lane >> 4;
-
-  // ---- F[a][c] = p1 T[d + a][c] - p0 sum_q J[a][q] T[q][c]   (T lower triangular)
-  for (int idx = tid; idx < d * W2; idx += 256) {
-    const int a = idx / W2, c = idx % W2;
-    double acc = (c <= d + a) ? p[1] * T[size_t(d + a) * D + c] : 0.0;
-    if (c < d) {
-      double s = 0.0;
-      for (int q = c; q < d; ++q) s += Jg[a * d + q] * T[size_t(q) * D + c];
-      acc -= p[0] * s;
-    }
-    Fw[a * LDF + c] = acc;
-  }
-  for (int j = tid; j < d; j += 256) wz[j] = v.z[size_t(b) * d + j];
-  __syncthreads();
-  // ---- S = F F^T with MFMA: DD x DD tiles, K = W2
-  for (int tile = wv; tile < DD * DD; tile += 4) {
-    const int ta = tile / DD, tb = tile % DD;
-    if (tb > ta) continue;
-    double4_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 8
-    for (int s = 0; s < W2 / 4; ++s)
-      acc = MFMA64(Fw[(16 * ta + r) * LDF + 4 * s + g], Fw[(16 * tb + r) * LDF + 4 * s + g], acc);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) Sm[(16 * ta + g + 4 * q) * LDS_ + 16 * tb + r] = acc[q];
-  }
-  __syncthreads();
-  // ---- Cholesky of S in LDS (lower), whole workgroup
-  for (int c = 0; c < d; ++c) {
-    const double piv = sqrt(Sm[c * LDS_ + c]);
-    __syncthreads();
-    if (tid == 0) Sm[c * LDS_ + c] = piv;
-    for (int rr = c + 1 + tid; rr < d; rr += 256) Sm[rr * LDS_ + c] /= piv;
-    __syncthreads();
-    const int m = d - c - 1;
-    for (int idx = tid; idx < m * m; idx += 256) {
-      const int rr = c + 1 + idx / m, q = c + 1 + idx % m;
-      if (q <= rr) Sm[rr * LDS_ + q] -= Sm[rr * LDS_ + c] * Sm[q * LDS_ + c];
-    }
-    __syncthreads();
-  }
-  // ---- W = C^-1 F and wz = C^-1 z: one thread per column, no synchronisation needed
-  for (int c = tid; c < W2 + 1; c += 256) {
-    double* col = (c < W2) ? (Fw + c) : wz;
-    const int ld = (c < W2) ? LDF : 1;
-    for (int a = 0; a < d; ++a) {
-      const double w = col[a * ld] / Sm[a * LDS_ + a];
-      col[a * ld] = w;
-      for (int a2 = a + 1; a2 < d; ++a2) col[a2 * ld] -= Sm[a2 * LDS_ + a] * w;
-    }
-  }
-  __syncthreads();
-  // ---- tv = W^T wz ; mean update  m = m^- - L^- tv
-  for (int c = tid; c < W2; c += 256) {
-    double acc = 0.0;
-    for (int a = 0; a < d; ++a) acc += Fw[a * LDF + c] * wz[a];
-    tv[c] = acc;
-  }
-  __syncthreads();
-  const size_t sB = size_t(v.B);
-  double* mdst = v.mean + (size_t(arg.dst) * sB + b) * D;
-  for (int row = tid; row < D; row += 256) {
-    const double pr = p[row / d];
-    double acc = 0.0;
-    const int cmax = row < W2 ? row + 1 : W2;
-    for (int c = 0; c < cmax; ++c) acc += T[size_t(row) * D + c] * tv[c];
-    mdst[row] -= pr * acc;
-  }
-  // ---- strips: Y^T = W X^T, X^T -= W^T Y^T  on the first W2 columns; plain copy of the rest
-  double* __restrict__ Ln = v.U + (size_t(arg.dst) * sB + b) * D * D;
-  for (int st = wv; st < DT; st += 4) {
-    const int j0 = 16 * st;
-    const int row = j0 + r;
-    const double pr = p[row / d];
-    double X[W2 / 4];
-#pragma unroll
-    for (int s = 0; s < W2 / 4; ++s) {
-      const int c = 4 * s + g;
-      X[s] = (c <= row) ? pr * T[size_t(row) * D + c] : 0.0;
-    }
-    double4_t yT[DD];
-#pragma unroll
-    for (int ta = 0; ta < DD; ++ta) {
-      double4_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int s = 0; s < W2 / 4; ++s) acc = MFMA64(Fw[(16 * ta + r) * LDF + 4 * s + g], X[s], acc);
-      yT[ta] = acc;
-    }
-#pragma unroll
-    for (int t = 0; t < W2 / 16; ++t) {
-      double4_t c4 = {X[4 * t], X[4 * t + 1], X[4 * t + 2], X[4 * t + 3]};
-#pragma unroll
-      for (int kk = 0; kk < d / 4; ++kk) c4 = MFMA64(-Fw[(4 * kk + g) * LDF + 16 * t + r], yT[kk >> 2][kk & 3], c4);
-      X[4 * t] = c4[0];
-      X[4 * t + 1] = c4[1];
-      X[4 * t + 2] = c4[2];
-      X[4 * t + 3] = c4[3];
-    }
-#pragma unroll
-    for (int s = 0; s < W2 / 4; ++s) Ln[size_t(row) * D + 4 * s + g] = X[s];
-  }
-  for (int idx = tid; idx < D * (D - W2); idx += 256) {
-    const int row = idx / (D - W2), c = W2 + idx % (D - W2);
-    Ln[size_t(row) * D + c] = (c <= row) ? p[row / d] * T[size_t(row) * D + c] : 0.0;
-  }
-  __syncthreads();
-  // ---- normalised error norm
-  const double atol = v.atol[b], rtol = v.rtol[b];
-  double part = 0.0;
-  for (int j = tid; j < d; j += 256) {
-    const double rel = v.err[size_t(b) * d + j] / (atol + rtol * fabs(mdst[j]));
-    part += rel * rel;
-  }
-  part = wave_sum(part);
-  if (lane == 0) red[wv] = part;
-  __syncthreads();
-  if (tid == 0) {
-    v.errnorm[b] = sqrt((red[0] + red[1] + red[2] + red[3]) / double(d));
-    v.sigma[size_t(arg.dst) * sB + b] = v.sig_new[b];
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Second-generation begin / measurement-update kernels: small LDS footprints (several workgroups per
+// begin / measurement-update kernels: small LDS footprints (several workgroups per
 // CU hide the latency of the sequential d x d Cholesky), F/W kept in global memory (L2), and the
 // D x 2d strip update spread over B * DT/4 workgroups.
 // ---------------------------------------------------------------------------------------------
@@ -1187,11 +865,9 @@ static void launch_mfma(const DenseView& v, const StepArg* args, const IwpConst*
   auto mark = [&](int i) {
     if (ev) (void)hipEventRecord(ev->ev[i], s);
   };
-  if (v.ablate & (8 | 1024)) hipLaunchKernelGGL(dense_mt_kernel, dim3(64, v.B), dim3(256), 0, s, v, args, K);
+  if (v.ablate & 1024) hipLaunchKernelGGL(dense_mt_kernel, dim3(64, v.B), dim3(256), 0, s, v, args, K);
   mark(2);
-  if (v.ablate & 8) {
-    hipLaunchKernelGGL((dense_lq_mfma_kernel<DT>), dim3(v.B), dim3(256), 0, s, v, args, K);
-  } else if (v.ablate & 1024) {
+  if (v.ablate & 1024) {  // A/B: separate Mt kernel + all passes from Mt
     hipLaunchKernelGGL((dense_lq2_mfma_kernel<DT, false>), dim3(v.B), dim3(256), 0, s, v, args, K, 0);
   } else {
     hipLaunchKernelGGL((dense_lq2_mfma_kernel<DT, true>), dim3(v.B), dim3(256), 0, s, v, args, K, 0);
@@ -1199,28 +875,16 @@ static void launch_mfma(const DenseView& v, const StepArg* args, const IwpConst*
   }
   mark(3);
   constexpr int d = 16 * DD, W2 = 2 * d;
-  if (!(v.ablate & 16)) {
-    static_assert(DD <= 4, "the error norm is computed by strip block 0, which must cover the d rows of u");
-    hipLaunchKernelGGL((dense_gain_mfma_kernel<DT, DD>), dim3(v.B), dim3(256), 0, s, v, args, K);
-    const size_t shm2 = (size_t(d) * (W2 + 1) + W2 + 4) * sizeof(double);
-    static bool attr2 = false;
-    if (!attr2) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_strip_update_mfma_kernel<DT, DD>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, int(shm2));
-      attr2 = true;
-    }
-    hipLaunchKernelGGL((dense_strip_update_mfma_kernel<DT, DD>), dim3((DT + 3) / 4, v.B), dim3(256), shm2, s, v, args, K);
-    mark(4);
-    return;
+  static_assert(DD <= 4, "the error norm is computed by strip block 0, which must cover the d rows of u");
+  hipLaunchKernelGGL((dense_gain_mfma_kernel<DT, DD>), dim3(v.B), dim3(256), 0, s, v, args, K);
+  const size_t shm2 = (size_t(d) * (W2 + 1) + W2 + 4) * sizeof(double);
+  static bool attr2 = false;
+  if (!attr2) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_strip_update_mfma_kernel<DT, DD>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, int(shm2));
+    attr2 = true;
   }
-  const size_t shm = (size_t(d) * (W2 + 2) + size_t(d) * (d + 1) + d + W2 + 4 + kMaxN) * sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_correct_mfma_kernel<DT, DD>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, int(shm));
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((dense_correct_mfma_kernel<DT, DD>), dim3(v.B), dim3(256), shm, s, v, args, K);
+  hipLaunchKernelGGL((dense_strip_update_mfma_kernel<DT, DD>), dim3((DT + 3) / 4, v.B), dim3(256), shm2, s, v, args, K);
   mark(4);
 }
 

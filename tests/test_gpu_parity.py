@@ -254,6 +254,30 @@ def test_dense_mfma_path_matches_oracle_and_generic(hip_lib, N, nu):
     slow.close()
 
 
+def test_dense_maximum_size_generic_path(hip_lib):
+    """BASELINE config 5 size (Brusselator N=128: d=256, D=1024) and an un-instantiated tile count (N=64, nu=4:
+    D=640) run on the generic dense kernels; two steps against the oracle."""
+    for N, nu in ((128, 3), (64, 4)):
+        vf = V.brusselator(N)
+        tc = tcoeffs(vf, [brusselator_y0(N)[None]], nu)
+        batch = _dense_batch(vf, nu, "ts1", 1)
+        batch.set_initial(np.stack(tc, axis=1), np.zeros(1), np.ones(1))
+        batch.set_tolerances(1e-5, 1e-5)
+        cfg = po.SolverConfig(nu=nu, model="dense", correction="ts1", strategy="filter", calibration="dynamic")
+        acfg = po.AdaptiveConfig(1e-5, 1e-5)
+        st = po.initial_state(cfg, [c[0] for c in tc], 0.0)
+        prob = oracle_problem(vf)
+        err = np.zeros(1)
+        for dt in (0.005, 0.01):
+            batch.attempt_step(np.full(1, dt), np.ones(1, np.uint8), err)
+            batch.commit(np.ones(1, np.uint8))
+            e, st = po.step(cfg, prob, st, dt)
+            en = po.normalise_error(acfg, e, st.mean[0], st.mean[0])
+            assert abs(err[0] - en) <= 1e-8 * en
+            assert relmax(batch.read_mean(0)[0, 0], st.mean[0]) < 1e-12
+        batch.close()
+
+
 def test_vdp_golden_prefix_through_api(hip_lib, golden):
     """Reference experiment 1 (vdp.py:52-80): stiff Van der Pol, dense EKF1 nu=4, tol 1e-3. The first
     25 accepted grid points agree with the committed JAX grid to rounding (see test_oracle_golden for
