@@ -545,6 +545,122 @@ int pnode_solve_adaptive_save_at(pnode_batch* h, const double* save_at, int32_t 
   return PNODE_OK;
 }
 
+int pnode_solve_adaptive_save_at_device(pnode_batch* h, const double* save_at, int32_t num_save, int32_t per_traj,
+                                        const double* dt0, const pnode_control* ctrl, double nz, int32_t iters_per_launch,
+                                        int64_t* num_steps_out, int64_t* num_attempts_out, uint8_t* failed_out) {
+  if (!h || !save_at || !dt0 || !ctrl || !num_steps_out || !num_attempts_out || !failed_out)
+    return fail(PNODE_EINVAL, "null argument");
+  if (!h->initialised) return fail(PNODE_ESTATE, "set_initial has not been called");
+  if (h->dense) return fail(PNODE_EINVAL, "the device-resident controller is implemented for the isotropic model");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  const size_t B = h->cfg.batch;
+  const int K = num_save - 1;
+  if (K < 1 || K > h->cfg.num_checkpoints) return fail(PNODE_EINVAL, "num_save - 1 must be in 1..num_checkpoints");
+  auto sa = [&](size_t b, int i) { return per_traj ? save_at[b * num_save + i] : save_at[i]; };
+  for (size_t b = 0; b < B; ++b) {
+    for (int i = 1; i < num_save; ++i)
+      if (!(sa(b, i) > sa(b, i - 1))) return fail(PNODE_EINVAL, "save_at must be strictly increasing");
+    if (!(dt0[b] > 0.0)) return fail(PNODE_EINVAL, "dt0 must be positive");
+  }
+  const double rate = double(h->cfg.nu + 1);
+  ControlParams cp{ctrl->safety, ctrl->factor_min, ctrl->factor_max, ctrl->power_integral_unscaled / rate,
+                   ctrl->power_proportional_unscaled / rate, nz, ctrl->clip, iters_per_launch > 0 ? iters_per_launch : 4096};
+  TrajCtl* hCtl = nullptr;
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&hCtl), B * sizeof(TrajCtl)));
+  TrajCtl* zCtl = nullptr;
+  hipError_t e0 = hipHostGetDevicePointer(reinterpret_cast<void**>(&zCtl), hCtl, 0);
+  if (e0 != hipSuccess) {
+    (void)hipHostFree(hCtl);
+    return fail(PNODE_EDEVICE, hipGetErrorString(e0));
+  }
+  std::vector<double> dt(dt0, dt0 + B), log_prev(B, 0.0), tq(B, 0.0);
+  std::vector<int32_t> cursor(B, 1), slot(B, -1);
+  std::vector<int64_t> attempts(B, 0);
+  for (size_t b = 0; b < B; ++b) {
+    failed_out[b] = 0;
+    for (int i = 0; i < num_save; ++i) num_steps_out[b * num_save + i] = 0;
+  }
+  int rc = PNODE_OK;
+  for (;;) {
+    // ---- checkpoints reached by STEP_FROM (host bookkeeping mirrors the device controller state)
+    for (;;) {
+      bool any_over = false, any_corner = false;
+      for (size_t b = 0; b < B; ++b) {
+        slot[b] = -1;
+        if (cursor[b] > K || failed_out[b]) continue;
+        const double nxt = sa(b, cursor[b]);
+        if (h->t_sf[b] + nz >= nxt && h->t_sf[b] > nxt + nz) {
+          slot[b] = cursor[b] - 1;
+          tq[b] = nxt;
+          any_over = true;
+        }
+      }
+      if (any_over) {
+        rc = pnode_interpolate(h, tq.data(), slot.data());
+        if (rc != PNODE_OK) break;
+        for (size_t b = 0; b < B; ++b)
+          if (slot[b] >= 0) {
+            num_steps_out[b * num_save + cursor[b]] = h->steps[b];
+            cursor[b] += 1;
+          }
+      }
+      for (size_t b = 0; b < B; ++b) {
+        slot[b] = -1;
+        if (cursor[b] > K || failed_out[b]) continue;
+        const double nxt = sa(b, cursor[b]);
+        if (h->t_sf[b] + nz >= nxt && !(h->t_sf[b] > nxt + nz)) {
+          slot[b] = cursor[b] - 1;
+          any_corner = true;
+        }
+      }
+      if (any_corner) {
+        rc = pnode_checkpoint_at_step(h, slot.data());
+        if (rc != PNODE_OK) break;
+        for (size_t b = 0; b < B; ++b)
+          if (slot[b] >= 0) {
+            num_steps_out[b * num_save + cursor[b]] = h->steps[b];
+            cursor[b] += 1;
+          }
+      }
+      if (!any_over && !any_corner) break;
+    }
+    if (rc != PNODE_OK) break;
+    // ---- hand the trajectories that still have a checkpoint ahead to the device controller
+    bool any = false;
+    for (size_t b = 0; b < B; ++b) {
+      TrajCtl& c = hCtl[b];
+      const bool act = cursor[b] <= K && !failed_out[b];
+      c.status = act ? 0 : -1;
+      if (!act) continue;
+      any = true;
+      c.t_sf = h->t_sf[b]; c.t_if = h->t_if[b]; c.dt = dt[b]; c.log_prev = log_prev[b]; c.t_stop = sa(b, cursor[b]);
+      c.steps = h->steps[b]; c.attempts = attempts[b];
+      c.s_sf = h->s_sf[b]; c.s_if = h->s_if[b]; c.s_pr = h->s_pr[b];
+    }
+    if (!any) break;
+    iso_launch_advance(h->iso, zCtl, h->dK, cp, h->stream);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) {
+      rc = fail(PNODE_EDEVICE, hipGetErrorString(e));
+      break;
+    }
+    for (size_t b = 0; b < B; ++b) {
+      const TrajCtl& c = hCtl[b];
+      if (c.status < 0) continue;
+      h->t_sf[b] = c.t_sf; h->t_if[b] = c.t_if; h->steps[b] = c.steps;
+      h->s_sf[b] = int8_t(c.s_sf); h->s_if[b] = int8_t(c.s_if); h->s_pr[b] = int8_t(c.s_pr);
+      h->pending[b] = 0;
+      dt[b] = c.dt; log_prev[b] = c.log_prev; attempts[b] = c.attempts;
+      if (c.status == 2) failed_out[b] = 1;
+    }
+  }
+  (void)hipHostFree(hCtl);
+  if (rc != PNODE_OK) return rc;
+  for (size_t b = 0; b < B; ++b) num_attempts_out[b] = attempts[b];
+  return PNODE_OK;
+}
+
 int pnode_solve_fixed_grid(pnode_batch* h, const double* grid, int32_t G, int32_t per_traj, double* u_out) {
   if (!h || !grid || !u_out || G < 1) return fail(PNODE_EINVAL, "bad argument");
   if (!h->initialised) return fail(PNODE_ESTATE, "set_initial has not been called");

@@ -32,6 +32,18 @@ struct InterpArg {
   int64_t steps;   // num_steps recorded with the checkpoint
 };
 
+// Device-resident controller state of one trajectory (iso_advance_kernel) and its parameters.
+struct TrajCtl {
+  double t_sf, t_if, dt, log_prev, t_stop;
+  int64_t steps, attempts;
+  int32_t s_sf, s_if, s_pr;
+  int32_t status;  // in: < 0 skip; out: 1 reached t_stop, 2 failed (non-finite), 3 iteration budget spent
+};
+struct ControlParams {
+  double safety, factor_min, factor_max, n1, n2, numerical_zero;
+  int32_t clip, max_iters;
+};
+
 // IWP(nu) constants in preconditioned coordinates, computed on the host in fp64.
 //   a[i][k]   = binom(nu-i, nu-k)           (upper triangular)
 //   qsT[c][i] = chol(Qbar)^T                (upper triangular),  Qbar[i][j] = 1/(2nu+1-i-j)

@@ -28,6 +28,7 @@ struct IsoView {
 
 void iso_launch_step(const IsoView& v, const StepArg* args, const IwpConst* K, hipStream_t s);
 void iso_launch_interp(const IsoView& v, const InterpArg* args, const IwpConst* K, hipStream_t s);
+void iso_launch_advance(const IsoView& v, TrajCtl* ctl, const IwpConst* K, const ControlParams& cp, hipStream_t s);
 void iso_launch_smooth(const IsoView& v, const int32_t* num_filled, double* out, hipStream_t s);
 
 // Dense model (EKF1 / EKF0 with a full D x D factor), D = n*d.

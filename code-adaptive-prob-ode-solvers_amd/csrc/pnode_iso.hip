@@ -202,20 +202,12 @@ __device__ __forceinline__ void store_small(double* __restrict__ dst, const doub
 // The fused attempted step
 // ---------------------------------------------------------------------------------------------
 
+// One attempted step of trajectory b by one wavefront: reads slot arg.src, writes slot arg.dst, returns the
+// normalised error norm (wave-uniform). ybuf [k][d] and zbuf [d] are this wave's LDS scratch.
 template <int N, bool FP>
-__global__ __launch_bounds__(256) void iso_step_kernel(IsoView v, const StepArg* __restrict__ args,
-                                                       const IwpConst* __restrict__ Kc) {
-  extern __shared__ double smem[];
-  const int lane = threadIdx.x & 63;
-  const int wv = threadIdx.x >> 6;
-  const int b = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv);
-  if (b >= v.B) return;
-  const StepArg arg = args[b];
-  if (!arg.active) return;
-  const IwpConst& K = *Kc;
+__device__ __forceinline__ double iso_attempt(const IsoView& v, const IwpConst& K, int b, int lane, const StepArg& arg,
+                                              double* ybuf, double* zbuf) {
   const int d = v.d, k = v.k;
-  double* ybuf = smem + size_t(wv) * (size_t(k) + 1) * d;  // [k][d] staged state for the vector field
-  double* zbuf = ybuf + size_t(k) * d;                     // [d] residual
 
   const double dt = arg.dt;
   double p[N], pinv[N];
@@ -335,10 +327,83 @@ __global__ __launch_bounds__(256) void iso_step_kernel(IsoView v, const StepArg*
     acc2 += rel * rel;
   }
   acc2 = wave_sum(acc2);
-  if (lane == 0) {
-    v.errnorm[b] = sqrt(acc2 / double(d));
-    v.sigma[size_t(arg.dst) * sB + b] = sigma;
+  if (lane == 0) v.sigma[size_t(arg.dst) * sB + b] = sigma;
+  return sqrt(acc2 / double(d));
+}
+
+template <int N, bool FP>
+__global__ __launch_bounds__(256) void iso_step_kernel(IsoView v, const StepArg* __restrict__ args,
+                                                       const IwpConst* __restrict__ Kc) {
+  extern __shared__ double smem[];
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const int b = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv);
+  if (b >= v.B) return;
+  const StepArg arg = args[b];
+  if (!arg.active) return;
+  double* ybuf = smem + size_t(wv) * (size_t(v.k) + 1) * v.d;  // [k][d] staged state for the vector field
+  double* zbuf = ybuf + size_t(v.k) * v.d;                     // [d] residual
+  const double e = iso_attempt<N, FP>(v, *Kc, b, lane, arg, ybuf, zbuf);
+  if (lane == 0) v.errnorm[b] = e;
+}
+
+// Device-resident controller (opt-in): every wavefront runs the accept/reject loop and the PI
+// step-size law for ITS trajectory until the next save_at point is reached (or an iteration budget is spent), so
+// the host synchronises once per checkpoint interval instead of once per attempted step. Same arithmetic as the
+// host controller in pnode_solve_adaptive_save_at.
+template <int N, bool FP>
+__global__ __launch_bounds__(256) void iso_advance_kernel(IsoView v, TrajCtl* __restrict__ ctl, const IwpConst* __restrict__ Kc,
+                                                          ControlParams cp) {
+  extern __shared__ double smem[];
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const int b = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv);
+  if (b >= v.B) return;
+  TrajCtl c = ctl[b];
+  if (c.status < 0) return;
+  double* ybuf = smem + size_t(wv) * (size_t(v.k) + 1) * v.d;
+  double* zbuf = ybuf + size_t(v.k) * v.d;
+  int iters = 0;
+  c.status = 0;
+  while (c.t_sf + cp.numerical_zero < c.t_stop && iters < cp.max_iters) {
+    double dt = c.dt;
+    if (cp.clip) dt = fmin(dt, c.t_stop - c.t_sf);
+    StepArg arg;
+    arg.dt = dt; arg.t = c.t_sf; arg.src = c.s_sf; arg.dst = c.s_pr; arg.active = 1; arg.pad = 0;
+    const double e = iso_attempt<N, FP>(v, *Kc, b, lane, arg, ybuf, zbuf);
+    __threadfence_block();  // the slot written by this attempt is read by the next one (other lanes of this wave)
+    ++iters;
+    c.attempts += 1;
+    bool accept;
+    if (e != e) {
+      c.status = 2;  // NaN error estimate: stop (the reference accepts the NaN state and fails later)
+      accept = true;
+    } else {
+      const double le = log(e);
+      const double raw = cp.safety * exp(cp.n2 * c.log_prev - (cp.n1 + cp.n2) * le);
+      const double factor = fmax(cp.factor_min, fmin(raw, cp.factor_max));
+      if (e <= 1.0) c.log_prev = le;
+      c.dt = factor * dt;
+      accept = !(e > 1.0);
+    }
+    if (accept) {
+      c.s_if = c.s_sf;
+      c.t_if = c.t_sf;
+      c.s_sf = c.s_pr;
+      c.t_sf += dt;
+      c.steps += 1;
+      int fr = 0;
+      while (fr == c.s_if || fr == c.s_sf) ++fr;
+      c.s_pr = fr;
+    }
+    if (c.status == 2) break;
+    if (!(isfinite(c.dt) && isfinite(c.t_sf) && c.dt > 0.0)) {
+      c.status = 2;
+      break;
+    }
   }
+  if (c.status == 0) c.status = (c.t_sf + cp.numerical_zero >= c.t_stop) ? 1 : 3;
+  if (lane == 0) ctl[b] = c;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -628,6 +693,20 @@ void iso_launch_step(const IsoView& v, const StepArg* args, const IwpConst* K, h
 }
 void iso_launch_interp(const IsoView& v, const InterpArg* args, const IwpConst* K, hipStream_t s) {
 #define CALL(NN) launch_interp_n<NN>(v, args, K, s)
+  PNODE_DISPATCH_N(v.n, CALL)
+#undef CALL
+}
+template <int N>
+static void launch_advance_n(const IsoView& v, TrajCtl* ctl, const IwpConst* K, const ControlParams& cp, hipStream_t s) {
+  const int blocks = (v.B + 3) / 4;
+  const size_t shm = size_t(4) * (size_t(v.k) + 1) * v.d * sizeof(double);
+  if (v.fixedpoint)
+    hipLaunchKernelGGL((iso_advance_kernel<N, true>), dim3(blocks), dim3(256), shm, s, v, ctl, K, cp);
+  else
+    hipLaunchKernelGGL((iso_advance_kernel<N, false>), dim3(blocks), dim3(256), shm, s, v, ctl, K, cp);
+}
+void iso_launch_advance(const IsoView& v, TrajCtl* ctl, const IwpConst* K, const ControlParams& cp, hipStream_t s) {
+#define CALL(NN) launch_advance_n<NN>(v, ctl, K, cp, s)
   PNODE_DISPATCH_N(v.n, CALL)
 #undef CALL
 }

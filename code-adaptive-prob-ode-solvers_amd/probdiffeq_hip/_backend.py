@@ -22,7 +22,7 @@ CALIBRATION = {"none": 0, "dynamic": 1}
 SYMBOLS = (
     "pnode_last_error pnode_version pnode_device_count pnode_create pnode_destroy pnode_set_initial "
     "pnode_set_tolerances pnode_attempt_step pnode_commit pnode_interpolate pnode_checkpoint_at_step "
-    "pnode_solve_fixed_grid pnode_solve_adaptive_save_at pnode_read_mean pnode_read_time pnode_read_output_scale pnode_read_factor "
+    "pnode_solve_fixed_grid pnode_solve_adaptive_save_at pnode_solve_adaptive_save_at_device pnode_read_mean pnode_read_time pnode_read_output_scale pnode_read_factor "
     "pnode_read_checkpoint_means pnode_smooth_checkpoint_means pnode_last_step_ms pnode_set_phase_timing "
     "pnode_last_phase_ms pnode_set_generic_path pnode_stream"
 ).split()
@@ -95,6 +95,8 @@ def load_library():
     lib.pnode_solve_fixed_grid.argtypes = [vp, dp, C.c_int32, C.c_int32, dp]
     lib.pnode_solve_adaptive_save_at.argtypes = [vp, dp, C.c_int32, C.c_int32, dp, C.POINTER(PnodeControl), C.c_double,
                                                  C.c_int64, i64p, i64p, u8p]
+    lib.pnode_solve_adaptive_save_at_device.argtypes = [vp, dp, C.c_int32, C.c_int32, dp, C.POINTER(PnodeControl), C.c_double,
+                                                        C.c_int32, i64p, i64p, u8p]
     lib.pnode_read_mean.argtypes = [vp, C.c_int32, dp]
     lib.pnode_read_time.argtypes = [vp, dp, i64p]
     lib.pnode_read_output_scale.argtypes = [vp, C.c_int32, dp]
@@ -210,8 +212,9 @@ class Batch:
         slot = np.ascontiguousarray(slot, dtype=np.int32)
         _check(self._lib.pnode_checkpoint_at_step(self._h, slot.ctypes.data_as(C.POINTER(C.c_int32))))
 
-    def solve_adaptive_save_at(self, save_at, dt0, control, numerical_zero, max_attempts=0):
-        """Native driver loop (controller + checkpoints on the host, in C++). Returns (num_steps, num_attempts, failed)."""
+    def solve_adaptive_save_at(self, save_at, dt0, control, numerical_zero, max_attempts=0, device_controller=False):
+        """Native driver loop (controller + checkpoints on the host, in C++; or, opt-in, the controller on the
+        device). Returns (num_steps, num_attempts, failed)."""
         save_at = _f64(save_at)
         per_traj = int(save_at.ndim == 2)
         num_save = save_at.shape[-1]
@@ -221,10 +224,10 @@ class Batch:
         attempts = np.zeros(self.B, dtype=np.int64)
         failed = np.zeros(self.B, dtype=np.uint8)
         dt0 = _f64(np.broadcast_to(dt0, (self.B,)))
-        _check(self._lib.pnode_solve_adaptive_save_at(
-            self._h, _dp(save_at), num_save, per_traj, _dp(dt0), C.byref(ctrl), float(numerical_zero), int(max_attempts),
-            steps.ctypes.data_as(C.POINTER(C.c_int64)), attempts.ctypes.data_as(C.POINTER(C.c_int64)),
-            failed.ctypes.data_as(C.POINTER(C.c_uint8))))
+        fn = self._lib.pnode_solve_adaptive_save_at_device if device_controller else self._lib.pnode_solve_adaptive_save_at
+        _check(fn(self._h, _dp(save_at), num_save, per_traj, _dp(dt0), C.byref(ctrl), float(numerical_zero), int(max_attempts),
+                  steps.ctypes.data_as(C.POINTER(C.c_int64)), attempts.ctypes.data_as(C.POINTER(C.c_int64)),
+                  failed.ctypes.data_as(C.POINTER(C.c_uint8))))
         return steps, attempts, failed.astype(bool)
 
     def solve_fixed_grid(self, grid):

@@ -203,13 +203,17 @@ def _python_save_at_loop(batch, loop, sa_b, K, nz):
 
 
 def solve_adaptive_save_at(vector_field, initial_condition: InitialCondition, save_at, adaptive_solver: AdaptiveSolver,
-                           dt0, *, device=None, python_controller=False) -> Solution:
+                           dt0, *, device=None, python_controller=False, device_controller=False) -> Solution:
     """Adaptive solve that stores the solution at `save_at` only (fixed memory, O(len(save_at))).
 
     save_at: (K+1,) shared or (B, K+1) per trajectory; save_at[..., 0] is the initial time. Steps are
     not clipped (unless control.clip): an accepted step that oversteps a checkpoint is interpolated.
     With strategy_fixedpoint, `Solution.u` holds the smoothed means (backward pass over the stored
     checkpoint transitions), as probdiffeq's solution object does.
+
+    Controller placement: by default the PI controller and the accept/reject decisions run on the host (native
+    loop inside the C-ABI; `python_controller=True` runs the same loop in NumPy). `device_controller=True`
+    (isotropic model) moves them into the step kernel: one host synchronisation per checkpoint interval.
     """
     solver = adaptive_solver.solver
     if not solver.strategy.is_suitable_for_save_at:
@@ -230,7 +234,8 @@ def solve_adaptive_save_at(vector_field, initial_condition: InitialCondition, sa
     else:
         # native driver: same controller arithmetic and call sequence, in C++ inside libpnode_hip.so
         num_steps, attempts, failed = batch.solve_adaptive_save_at(sa if sa.ndim == 1 else sa_b, loop.dt, adaptive_solver.control,
-                                                                   adaptive_solver.numerical_zero)
+                                                                   adaptive_solver.numerical_zero,
+                                                                   device_controller=device_controller)
         loop.attempts, loop.failed = attempts, failed
         cursor = np.where(failed, 1 + np.argmax(np.concatenate([num_steps[:, 1:] == 0, np.ones((B, 1), bool)], axis=1), axis=1),
                           K + 1)

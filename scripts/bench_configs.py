@@ -21,7 +21,7 @@ from probdiffeq_hip import ivpsolve, ivpsolvers, taylor  # noqa: E402
 from probdiffeq_hip.impl import impl  # noqa: E402
 
 
-def run(name, vf, u0s, t0, t1, *, model, corr, strategy, nu, atol, rtol, dt0, num_save=5, truth=None):
+def run(name, vf, u0s, t0, t1, *, model, corr, strategy, nu, atol, rtol, dt0, num_save=5, truth=None, device_controller=False):
     import warnings
 
     warnings.simplefilter("ignore")
@@ -38,12 +38,14 @@ def run(name, vf, u0s, t0, t1, *, model, corr, strategy, nu, atol, rtol, dt0, nu
     # warm-up (first launch compiles nothing but pages code in)
     ivpsolve.solve_adaptive_save_at(vf, init, save_at=np.linspace(t0, t0 + 1e-3 * (t1 - t0), 2), dt0=dt0, adaptive_solver=asolver)
     tic = time.perf_counter()
-    sol = ivpsolve.solve_adaptive_save_at(vf, init, save_at=save_at, dt0=dt0, adaptive_solver=asolver)
+    sol = ivpsolve.solve_adaptive_save_at(vf, init, save_at=save_at, dt0=dt0, adaptive_solver=asolver,
+                                          device_controller=device_controller)
     el = time.perf_counter() - tic
     acc = int(np.sum(sol.num_steps[..., -1]))
     att = int(np.sum(sol.num_attempts))
     B = init.tcoeffs.shape[0]
     out = {"config": name, "batch": B, "d": d, "nu": nu, "model": model, "correction": corr, "strategy": strategy,
+           "controller": "device" if device_controller else "host",
            "accepted_steps": acc, "attempted_steps": att, "seconds": round(el, 4),
            "accepted_steps_per_s": acc / el, "finite": bool(np.all(np.isfinite(sol.u)))}
     if truth is not None:
@@ -87,6 +89,19 @@ def main():
         atol=1e-6, rtol=1e-6, dt0=0.01)
     run("C4 brusselator dense EKF1 nu=3", vf, [y0], 0.0, 10.0, model="dense", corr="ts1", strategy="filter", nu=3,
         atol=1e-6, rtol=1e-6, dt0=0.01)
+    # opt-in device-resident controller on the latency-bound isotropic configurations
+    run("C4 brusselator iso EKF0 nu=3", vf, [y0], 0.0, 10.0, model="isotropic", corr="ts0", strategy="filter", nu=3,
+        atol=1e-6, rtol=1e-6, dt0=0.01, device_controller=True)
+    run("C4 brusselator iso EKF0 nu=4 fixedpoint 200 ckpts", vf, [y0], 0.0, 10.0, model="isotropic", corr="ts0",
+        strategy="fixedpoint", nu=4, atol=1e-8, rtol=1e-8, dt0=0.01, num_save=200)
+    run("C4 brusselator iso EKF0 nu=4 fixedpoint 200 ckpts", vf, [y0], 0.0, 10.0, model="isotropic", corr="ts0",
+        strategy="fixedpoint", nu=4, atol=1e-8, rtol=1e-8, dt0=0.01, num_save=200, device_controller=True)
+    vf, u0, (t0, t1), _ = ivps.rigid_body(time_span=(0.0, 50.0))
+    run("C3 rigid body nu=3 sweep", vf, [np.tile(u0[0], (256, 1))], t0, t1, model="isotropic", corr="ts0",
+        strategy="fixedpoint", nu=3, atol=1e-3 * rt, rtol=rt, dt0=0.1, device_controller=True)
+    vf, u0, (t0, t1), _ = ivps.van_der_pol_first_order(1.0)
+    run("C1 vdp mu=1 (single)", vf, [u0[0]], t0, t1, model="isotropic", corr="ts0", strategy="filter", nu=3,
+        atol=1e-6, rtol=1e-6, dt0=0.1, device_controller=True)
 
 
 if __name__ == "__main__":

@@ -387,3 +387,45 @@ def test_pleiades_second_order_isotropic(hip_lib, golden):
     sm = po.markov_marginals_reverse(cfg, osol)[:, 0]
     assert abs(int(aux["solution"].num_steps[-1]) - int(osol.num_steps[-1])) <= 0.05 * osol.num_steps[-1]
     assert np.max(np.abs(sol - sm)) < 1e-6
+
+
+def test_device_resident_controller_matches_host_controller(hip_lib, golden):
+    """the accept/reject loop + PI law inside the kernel (one wavefront per trajectory) must
+    reproduce the host-controlled solve: reference Brusselator configuration (bit-exact step count vs the golden
+    vector) and a rigid-body tolerance sweep with per-trajectory save_at grids."""
+    from probdiffeq_hip import taylor
+
+    g = golden["brusselator"]
+    N = 16
+    vf = V.brusselator(N)
+    impl.select("isotropic", ode_shape=(2 * N,))
+    solver = ivpsolvers.solver_dynamic(ivpsolvers.strategy_fixedpoint(ivpsolvers.prior_ibm(4), ivpsolvers.correction_ts0()))
+    y0 = np.stack([brusselator_y0(N, ph) for ph in (0.0, 0.9)])
+    init = solver.initial_condition(taylor.odejet_unroll(vf, [y0], num=4), 1.0)
+    asolver = ivpsolve.adaptive(solver, atol=1e-8, rtol=1e-8)
+    host = ivpsolve.solve_adaptive_save_at(vf, init, save_at=g["ts"], dt0=0.01, adaptive_solver=asolver)
+    dev = ivpsolve.solve_adaptive_save_at(vf, init, save_at=g["ts"], dt0=0.01, adaptive_solver=asolver, device_controller=True)
+    i = list(g["N"]).index(N)
+    assert int(dev.num_steps[0, -1]) == int(g["num_steps_checkpoint"][i])
+    assert np.array_equal(dev.num_steps, host.num_steps)
+    assert np.array_equal(dev.num_attempts, host.num_attempts)
+    assert np.max(np.abs(dev.u - host.u)) < 1e-11
+    assert np.max(np.abs(dev.u[0] - g[f"ys_N{N}"])) < 1e-9
+    # filter, tolerance sweep, per-trajectory checkpoints
+    vf = V.rigid_body()
+    tols = 10.0 ** np.array([-3.0, -4.0, -5.0, -6.0])
+    B = len(tols)
+    impl.select("isotropic", ode_shape=(3,))
+    solver = ivpsolvers.solver_dynamic(ivpsolvers.strategy_filter(ivpsolvers.prior_ibm(3), ivpsolvers.correction_ts0()))
+    u0 = np.tile(np.array([1.0, 0.0, 0.9]), (B, 1))
+    init = solver.initial_condition(tcoeffs(vf, [u0], 3), 1.0)
+    save_at = np.stack([np.linspace(0.0, 5.0 + b, 7) for b in range(B)])
+    asolver = ivpsolve.adaptive(solver, atol=1e-3 * tols, rtol=tols)
+    host = ivpsolve.solve_adaptive_save_at(vf, init, save_at=save_at, dt0=0.1, adaptive_solver=asolver)
+    dev = ivpsolve.solve_adaptive_save_at(vf, init, save_at=save_at, dt0=0.1, adaptive_solver=asolver, device_controller=True)
+    assert np.array_equal(dev.num_steps, host.num_steps)
+    assert np.max(np.abs(dev.u - host.u)) < 1e-10
+    # and the Python/NumPy driver agrees with the native host driver
+    py = ivpsolve.solve_adaptive_save_at(vf, init, save_at=save_at, dt0=0.1, adaptive_solver=asolver, python_controller=True)
+    assert np.array_equal(py.num_steps, host.num_steps)
+    assert np.max(np.abs(py.u - host.u)) < 1e-10
