@@ -643,10 +643,10 @@ __global__ __launch_bounds__(256, 2) void dense_gain_mfma_kernel(DenseView v, co
     double4_t acc;
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[q] = p1 * T[size_t(d + 16 * ta + g + 4 * q) * D + 16 * tc + r];
-    for (int s = 4 * tc; s < d / 4; ++s) {  // rows q >= 16 tc of the triangular block contribute
+#pragma unroll
+    for (int s = 0; s < d / 4; ++s) {  // T[0:d,0:d] is lower triangular: its upper part is stored as zeros
       const int qq = 4 * s + g;
-      const double bv = (16 * tc + r <= qq) ? T[size_t(qq) * D + 16 * tc + r] : 0.0;
-      acc = MFMA64(-p0 * Jg[(16 * ta + r) * d + qq], bv, acc);
+      acc = MFMA64(-p0 * Jg[(16 * ta + r) * d + qq], T[size_t(qq) * D + 16 * tc + r], acc);
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) F[(16 * ta + g + 4 * q) * W2 + 16 * tc + r] = acc[q];
@@ -657,7 +657,7 @@ __global__ __launch_bounds__(256, 2) void dense_gain_mfma_kernel(DenseView v, co
     const int ta = tile / DD, tb = tile % DD;
     if (tb > ta) continue;
     double4_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 8
+#pragma unroll
     for (int s = 0; s < W2 / 4; ++s)
       acc = MFMA64(F[(16 * ta + r) * W2 + 4 * s + g], F[(16 * tb + r) * W2 + 4 * s + g], acc);
 #pragma unroll
@@ -665,6 +665,9 @@ __global__ __launch_bounds__(256, 2) void dense_gain_mfma_kernel(DenseView v, co
   }
   __syncthreads();
   lds_cholesky_blocked<DD, LD>(Sm, tid);
+  __shared__ double invd[d];
+  if (tid < d) invd[tid] = 1.0 / Sm[tid * LD + tid];
+  __syncthreads();
   // one thread per column of F (and one for z): register-resident forward substitution
   if (tid <= W2) {
     double col[d];
@@ -677,10 +680,10 @@ __global__ __launch_bounds__(256, 2) void dense_gain_mfma_kernel(DenseView v, co
     }
 #pragma unroll
     for (int a = 0; a < d; ++a) {
-      const double w = col[a] / Sm[a * LD + a];
+      const double w = col[a] * invd[a];
       col[a] = w;
 #pragma unroll
-      for (int a2 = a + 1; a2 < d; ++a2) col[a2] -= Sm[a2 * LD + a] * w;
+      for (int a2 = a + 1; a2 < d; ++a2) col[a2] = fma(-Sm[a2 * LD + a], w, col[a2]);
     }
     if (tid < W2) {
 #pragma unroll
@@ -694,6 +697,7 @@ __global__ __launch_bounds__(256, 2) void dense_gain_mfma_kernel(DenseView v, co
   __syncthreads();  // W (global, this workgroup) and the solved wz are visible
   if (tid < W2) {
     double acc = 0.0;
+#pragma unroll 16
     for (int a = 0; a < d; ++a) acc += F[a * W2 + tid] * wz[a];
     v.X[size_t(b) * D * d + tid] = acc;  // tv lives at the head of the X scratch
   }
@@ -757,14 +761,23 @@ __global__ __launch_bounds__(256, 2) void dense_strip_update_mfma_kernel(DenseVi
 #pragma unroll
       for (int i = 1; i < kMaxN; ++i) pr = (i == iblk) ? p[i] : pr;
     }
+    // register strip in the HBM layout  X[16 T + 4 j + q] = p_r T[row][64 T + 16 g + 4 j + q]  (128 B per lane
+    // and super-tile); T's upper triangle is stored as zeros, so no predicate is needed
     double X[W2 / 4];
     double mpart = 0.0;
+    const double* __restrict__ trow = T + size_t(row) * D + 16 * g;
 #pragma unroll
-    for (int s = 0; s < W2 / 4; ++s) {
-      const int c = 4 * s + g;
-      X[s] = (c <= row) ? pr * T[size_t(row) * D + c] : 0.0;
-      mpart += X[s] * tv[c];
-    }
+    for (int T4 = 0; T4 < W2 / 64; ++T4)
+#pragma unroll
+      for (int e = 0; e < 16; e += 2) {
+        const double2 t2 = *reinterpret_cast<const double2*>(trow + 64 * T4 + e);
+        X[16 * T4 + e] = pr * t2.x;
+        X[16 * T4 + e + 1] = pr * t2.y;
+      }
+#pragma unroll
+    for (int T4 = 0; T4 < W2 / 64; ++T4)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mpart = fma(X[16 * T4 + e], tv[64 * T4 + 16 * g + e], mpart);
     mpart += __shfl_xor(mpart, 16, kWave);
     mpart += __shfl_xor(mpart, 32, kWave);
     if (g == 0) mdst[row] -= mpart;
@@ -772,25 +785,46 @@ __global__ __launch_bounds__(256, 2) void dense_strip_update_mfma_kernel(DenseVi
     double4_t yT[DD];
 #pragma unroll
     for (int ta = 0; ta < DD; ++ta) {
-      double4_t acc = {0.0, 0.0, 0.0, 0.0};
+      double4_t a0 = {0.0, 0.0, 0.0, 0.0}, a1 = a0;
 #pragma unroll
-      for (int s = 0; s < W2 / 4; ++s) acc = MFMA64(Fw[(16 * ta + r) * LDF + 4 * s + g], X[s], acc);
-      yT[ta] = acc;
+      for (int T4 = 0; T4 < W2 / 64; ++T4)
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+          const double* wrow = Fw + (16 * ta + r) * LDF + 64 * T4 + 16 * g + e;
+          a0 = MFMA64(wrow[0], X[16 * T4 + e], a0);
+          a1 = MFMA64(wrow[1], X[16 * T4 + e + 1], a1);
+        }
+      yT[ta] = a0 + a1;
       __builtin_amdgcn_sched_barrier(0);
     }
+    const int coff = 16 * (r & 3) + (r >> 2);
 #pragma unroll
-    for (int t = 0; t < W2 / 16; ++t) {
-      double4_t c4 = {X[4 * t], X[4 * t + 1], X[4 * t + 2], X[4 * t + 3]};
+    for (int T4 = 0; T4 < W2 / 64; ++T4) {
 #pragma unroll
-      for (int kk = 0; kk < d / 4; ++kk) c4 = MFMA64(-Fw[(4 * kk + g) * LDF + 16 * t + r], yT[kk >> 2][kk & 3], c4);
-      X[4 * t] = c4[0];
-      X[4 * t + 1] = c4[1];
-      X[4 * t + 2] = c4[2];
-      X[4 * t + 3] = c4[3];
+      for (int j = 0; j < 4; ++j) {
+        double4_t c4 = {X[16 * T4 + 4 * j], X[16 * T4 + 4 * j + 1], X[16 * T4 + 4 * j + 2], X[16 * T4 + 4 * j + 3]};
+#pragma unroll
+        for (int kk = 0; kk < d / 4; ++kk)
+          c4 = MFMA64(-Fw[(4 * kk + g) * LDF + 64 * T4 + 4 * j + coff], yT[kk >> 2][kk & 3], c4);
+        X[16 * T4 + 4 * j] = c4[0];
+        X[16 * T4 + 4 * j + 1] = c4[1];
+        X[16 * T4 + 4 * j + 2] = c4[2];
+        X[16 * T4 + 4 * j + 3] = c4[3];
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
+    {
+      double* __restrict__ lrow = Ln + size_t(row) * D + 16 * g;
 #pragma unroll
-    for (int s = 0; s < W2 / 4; ++s) Ln[size_t(row) * D + 4 * s + g] = X[s];
+      for (int T4 = 0; T4 < W2 / 64; ++T4)
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+          double2 t2;
+          t2.x = X[16 * T4 + e];
+          t2.y = X[16 * T4 + e + 1];
+          *reinterpret_cast<double2*>(lrow + 64 * T4 + e) = t2;
+        }
+    }
     // the remaining columns of these 16 rows are plain (scaled) copies of the triangular factor
     {
       constexpr int NC = (D - W2) / kWave;  // column chunks per row
