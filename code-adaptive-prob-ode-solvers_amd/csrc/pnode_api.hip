@@ -100,6 +100,8 @@ struct pnode_batch {
   InterpArg* dIargs = nullptr;
   int32_t* dFilled = nullptr;
   double *dAtol = nullptr, *dRtol = nullptr, *dPrm = nullptr, *dErr = nullptr;
+  FpArg *hFp0 = nullptr, *hFp1 = nullptr, *zFp0 = nullptr, *zFp1 = nullptr;  // pinned + device views (dense fixedpoint)
+  InterpArg* zIargs = nullptr;
   StepArg* zArgs = nullptr;     // device view of hArgs (zero-copy: kernels read the per-step arguments over PCIe)
   double* zErr = nullptr;       // device view of hErr  (kernels write the error norms straight to pinned host memory)
   bool step_timing = false;
@@ -134,6 +136,8 @@ int pnode_destroy(pnode_batch* h) {
   if (h->hArgs) (void)hipHostFree(h->hArgs);
   if (h->hIargs) (void)hipHostFree(h->hIargs);
   if (h->hErr) (void)hipHostFree(h->hErr);
+  if (h->hFp0) (void)hipHostFree(h->hFp0);
+  if (h->hFp1) (void)hipHostFree(h->hFp1);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   for (auto& e : h->phase.ev)
@@ -166,8 +170,6 @@ int pnode_create(const pnode_config* cfg, pnode_batch** out) {
     return fail(PNODE_EINVAL, "correction_ts1 needs the dense model");
   if (cfg->strategy != PNODE_STRATEGY_FILTER && cfg->strategy != PNODE_STRATEGY_FIXEDPOINT)
     return fail(PNODE_EINVAL, "bad strategy");
-  if (cfg->model == PNODE_MODEL_DENSE && cfg->strategy != PNODE_STRATEGY_FILTER)
-    return fail(PNODE_EINVAL, "dense model: only strategy_filter is implemented");
   if (cfg->calibration != PNODE_CALIB_NONE && cfg->calibration != PNODE_CALIB_DYNAMIC)
     return fail(PNODE_EINVAL, "bad calibration");
   if (cfg->num_vf_params < 0 || cfg->num_vf_params > PNODE_MAX_VF_PARAMS) return fail(PNODE_EINVAL, "bad num_vf_params");
@@ -208,6 +210,11 @@ int pnode_create(const pnode_config* cfg, pnode_batch** out) {
   HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->hErr), B * sizeof(double)));
   HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->zArgs), h->hArgs, 0));
   HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->zErr), h->hErr, 0));
+  HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->zIargs), h->hIargs, 0));
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->hFp0), B * sizeof(FpArg)));
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->hFp1), B * sizeof(FpArg)));
+  HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->zFp0), h->hFp0, 0));
+  HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->zFp1), h->hFp1, 0));
 
   ALLOC(h->dK, 1);
   ALLOC(h->dArgs, B);
@@ -251,13 +258,28 @@ int pnode_create(const pnode_config* cfg, pnode_batch** out) {
     v.ablate = getenv("PNODE_ABLATE") ? atoi(getenv("PNODE_ABLATE")) : 0;
     v.dynamic = cfg->calibration == PNODE_CALIB_DYNAMIC;
     v.vf_id = cfg->vf_id; v.P = cfg->num_vf_params; v.prm_per_traj = cfg->vf_params_per_trajectory;
-    ALLOC(v.mean, 3 * B * n * d);
-    ALLOC(v.U, 3 * B * D * D);
-    ALLOC(v.sigma, 3 * B);
+    v.fixedpoint = cfg->strategy == PNODE_STRATEGY_FIXEDPOINT;
+    v.nslots = v.fixedpoint ? 5 : 3;
+    v.mr_rows = v.fixedpoint ? 2 : 1;
+    if (v.fixedpoint) v.force_generic = 1;  // the extra-row LQ of the smoother runs on the generic kernels
+    const size_t NS = v.nslots;
+    ALLOC(v.mean, NS * B * n * d);
+    ALLOC(v.U, NS * B * D * D);
+    ALLOC(v.sigma, NS * B);
     ALLOC(v.ck_mean, B * Kc * n * d);
     ALLOC(v.ck_steps, B * Kc);
-    ALLOC(v.M, B * D * D);
-    ALLOC(v.R, B * D * D);
+    ALLOC(v.M, B * v.mr_rows * D * D);
+    ALLOC(v.R, B * v.mr_rows * D * D);
+    ALLOC(v.act, B);
+    if (v.fixedpoint) {
+      ALLOC(v.mext, B * D);
+      ALLOC(v.cG, NS * B * D * D);
+      ALLOC(v.cxi, NS * B * D);
+      ALLOC(v.cLam, NS * B * D * D);
+      ALLOC(v.ck_G, B * Kc * D * D);
+      ALLOC(v.ck_xi, B * Kc * D);
+      ALLOC(v.ck_Lam, B * Kc * D * D);
+    }
     ALLOC(v.J, B * d * size_t(k) * d);
     ALLOC(v.z, B * d);
     ALLOC(v.err, B * d);
@@ -307,6 +329,15 @@ int pnode_set_initial(pnode_batch* h, const double* tcoeffs, const double* t0, c
     }
   } else {
     HIP_TRY(hipMemsetAsync(h->dn.U, 0, B * D * D * sizeof(double), h->stream));
+    if (h->dn.fixedpoint) {
+      std::vector<double> eye(B * D * D, 0.0);
+      for (size_t b = 0; b < B; ++b)
+        for (size_t i = 0; i < D; ++i) eye[(b * D + i) * D + i] = 1.0;
+      HIP_TRY(hipMemcpyAsync(h->dn.cG, eye.data(), B * D * D * sizeof(double), hipMemcpyHostToDevice, h->stream));
+      HIP_TRY(hipMemsetAsync(h->dn.cxi, 0, size_t(h->dn.nslots) * B * D * sizeof(double), h->stream));
+      HIP_TRY(hipMemsetAsync(h->dn.cLam, 0, size_t(h->dn.nslots) * B * D * D * sizeof(double), h->stream));
+      HIP_TRY(hipStreamSynchronize(h->stream));
+    }
   }
   HIP_TRY(hipStreamSynchronize(h->stream));
   for (size_t b = 0; b < B; ++b) {
@@ -360,6 +391,13 @@ int pnode_attempt_step(pnode_batch* h, const double* dt, const uint8_t* active, 
   // costs the launches plus one stream synchronisation (no hipMemcpy calls on the critical path)
   if (h->step_timing) HIP_TRY(hipEventRecord(h->ev0, h->stream));
   enqueue_step(h, h->zArgs);
+  if (h->dense && h->dn.fixedpoint) {
+    for (size_t b = 0; b < B; ++b) {
+      const StepArg& a = h->hArgs[b];
+      h->hFp0[b] = FpArg{a.dt, a.src, a.dst, 1, a.active, 0, 0};
+    }
+    dense_fp_launch_step_tail(h->dn, h->zFp0, h->dK, h->stream);
+  }
   if (h->step_timing) HIP_TRY(hipEventRecord(h->ev1, h->stream));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
@@ -411,7 +449,15 @@ static int run_interp(pnode_batch* h, const double* t, const int32_t* slot, bool
     }
   }
   HIP_TRY(hipMemcpyAsync(h->dIargs, h->hIargs, B * sizeof(InterpArg), hipMemcpyHostToDevice, h->stream));
-  if (h->dense)
+  if (h->dense && h->dn.fixedpoint) {
+    for (size_t b = 0; b < B; ++b) {
+      const InterpArg& a = h->hIargs[b];
+      const int32_t act = (a.ckpt >= 0 && !a.at_step) ? 1 : 0;
+      h->hFp0[b] = FpArg{a.t - a.t0, a.s0, 3, 1, act, 0, 0};  // t0 -> t, merged with the running transition
+      h->hFp1[b] = FpArg{a.t1 - a.t, 3, 4, 0, act, 0, 0};     // t -> t1 from the identity
+    }
+    dense_fp_launch_interp(h->dn, h->dIargs, h->zFp0, h->zFp1, h->dK, h->stream);
+  } else if (h->dense)
     dense_launch_interp(h->dn, h->dIargs, h->dK, h->stream);
   else
     iso_launch_interp(h->iso, h->dIargs, h->dK, h->stream);
@@ -425,8 +471,8 @@ static int run_interp(pnode_batch* h, const double* t, const int32_t* slot, bool
       int8_t fr = 0;
       while (fr == h->s_sf[b]) ++fr;
       h->s_pr[b] = fr;
-    } else if (!h->dense) {
-      h->t_if[b] = t[b];  // isotropic: INTERP_FROM was advanced to the checkpoint in place
+    } else if (!h->dense || h->dn.fixedpoint) {
+      h->t_if[b] = t[b];  // INTERP_FROM was advanced to the checkpoint in place
     }
   }
   return PNODE_OK;
@@ -664,6 +710,7 @@ int pnode_solve_adaptive_save_at_device(pnode_batch* h, const double* save_at, i
 int pnode_solve_fixed_grid(pnode_batch* h, const double* grid, int32_t G, int32_t per_traj, double* u_out) {
   if (!h || !grid || !u_out || G < 1) return fail(PNODE_EINVAL, "bad argument");
   if (!h->initialised) return fail(PNODE_ESTATE, "set_initial has not been called");
+  if (h->dense && h->dn.fixedpoint) return fail(PNODE_EINVAL, "solve_fixed_grid: use strategy_filter with the dense model");
   HIP_TRY(hipSetDevice(h->cfg.device));
   const size_t B = h->cfg.batch, n = h->n, d = h->cfg.d;
   std::vector<StepArg> all(size_t(G) * B);
@@ -795,7 +842,8 @@ int pnode_read_checkpoint_means(pnode_batch* h, double* out) {
 
 int pnode_smooth_checkpoint_means(pnode_batch* h, const int32_t* num_filled, double* out) {
   if (!h || !num_filled || !out) return fail(PNODE_EINVAL, "null argument");
-  if (h->dense || !h->iso.fixedpoint) return fail(PNODE_EINVAL, "smoothing needs the isotropic fixedpoint strategy");
+  if ((h->dense && !h->dn.fixedpoint) || (!h->dense && !h->iso.fixedpoint))
+    return fail(PNODE_EINVAL, "smoothing needs the fixedpoint strategy");
   HIP_TRY(hipSetDevice(h->cfg.device));
   const size_t B = h->cfg.batch, K = h->cfg.num_checkpoints;
   for (size_t b = 0; b < B; ++b)
@@ -807,7 +855,10 @@ int pnode_smooth_checkpoint_means(pnode_batch* h, const int32_t* num_filled, dou
   if (e == hipSuccess)
     e = hipMemcpyAsync(h->dFilled, num_filled, B * sizeof(int32_t), hipMemcpyHostToDevice, h->stream);
   if (e == hipSuccess) {
-    iso_launch_smooth(h->iso, h->dFilled, dOut, h->stream);
+    if (h->dense)
+      dense_fp_launch_smooth(h->dn, h->dFilled, dOut, h->stream);
+    else
+      iso_launch_smooth(h->iso, h->dFilled, dOut, h->stream);
     e = hipMemcpyAsync(out, dOut, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream);
   }
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);

@@ -32,6 +32,16 @@ struct InterpArg {
   int64_t steps;   // num_steps recorded with the checkpoint
 };
 
+// One "predict with backward transition" operation of the dense fixed-point smoother, per trajectory.
+struct FpArg {
+  double dt;
+  int32_t src;         // slot providing mean / L (and, if merge, the running backward transition)
+  int32_t dst;         // slot receiving the (merged) transition; mean / L too when the op writes the state
+  int32_t merge;       // 1: compose with the transition of `src`; 0: start from the identity
+  int32_t active;
+  int32_t pad0, pad1;
+};
+
 // Device-resident controller state of one trajectory (iso_advance_kernel) and its parameters.
 struct TrajCtl {
   double t_sf, t_if, dt, log_prev, t_stop;

@@ -96,6 +96,7 @@ __global__ __launch_bounds__(kThreads) void dense_begin_kernel(DenseView v, cons
       for (int kk = i; kk < n; ++kk) acc += K.a[i][kk] * pinv[kk] * msrc[kk * d + j];
       const double e = p[i] * acc;
       mdst[i * d + j] = e;
+      if (v.fixedpoint) v.mext[size_t(b) * n * d + i * d + j] = e;
       if (i < k) ybuf[i * d + j] = e;
     }
   }
@@ -162,15 +163,19 @@ __global__ __launch_bounds__(kThreads) void dense_lq_input_kernel(DenseView v, c
                                                                   const IwpConst* __restrict__ Kc) {
   const int b = blockIdx.y;
   const StepArg arg = args[b];
-  if (!arg.active) return;
+  if (!arg.active) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) v.act[b] = 0;
+    return;
+  }
   const IwpConst& K = *Kc;
   const int d = v.d, n = v.n, D = v.D;
   double p[kMaxN], pinv[kMaxN];
   preconditioner_rt(n, arg.dt, K, p, pinv);
   const double sigma = v.sig_new[b];
   const double* L = v.U + (size_t(arg.src) * v.B + b) * D * D;
-  double* Mt = v.M + size_t(b) * D * D;
-  double* T = v.R + size_t(b) * D * D;
+  double* Mt = v.M + size_t(b) * v.mr_rows * D * D;
+  double* T = v.R + size_t(b) * v.mr_rows * D * D;
+  if (blockIdx.x == 0 && threadIdx.x == 0) v.act[b] = 1;
   for (int r = blockIdx.x; r < D; r += gridDim.x) {
     const int i = r / d, q = r % d;
     for (int c = threadIdx.x; c < D; c += kThreads) {
@@ -179,6 +184,10 @@ __global__ __launch_bounds__(kThreads) void dense_lq_input_kernel(DenseView v, c
       Mt[size_t(r) * D + c] = acc;
       const int j = c / d, q2 = c % d;
       T[size_t(r) * D + c] = (q2 == q && j <= i) ? sigma * K.qsT[j][i] : 0.0;
+      if (v.fixedpoint) {  // extra (never pivoted) rows [P^-1 L | 0]: they receive the backward transition
+        Mt[size_t(D + r) * D + c] = pinv[i] * L[size_t(r) * D + c];
+        T[size_t(D + r) * D + c] = 0.0;
+      }
     }
   }
 }
@@ -188,14 +197,15 @@ __global__ __launch_bounds__(kThreads) void dense_lq_input_kernel(DenseView v, c
 // Generic, unblocked: step c annihilates row c of Mt against the pivot T[c][c] and applies the
 // reflector to the rows below. One wave per row in the update.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void dense_lq_kernel(DenseView v, const StepArg* __restrict__ args) {
+// rows_total >= D: rows D .. rows_total-1 are updated by every reflector but never pivoted.
+__global__ __launch_bounds__(kThreads) void dense_lq_kernel(DenseView v, int rows_total) {
   __shared__ double red[4];
   __shared__ double sh_tau, sh_scale;
   const int b = blockIdx.x;
-  if (!args[b].active) return;
+  if (!v.act[b]) return;
   const int D = v.D;
-  double* Mt = v.M + size_t(b) * D * D;
-  double* T = v.R + size_t(b) * D * D;
+  double* Mt = v.M + size_t(b) * v.mr_rows * D * D;
+  double* T = v.R + size_t(b) * v.mr_rows * D * D;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   for (int c = 0; c < D; ++c) {
     double* x = Mt + size_t(c) * D;
@@ -218,7 +228,7 @@ __global__ __launch_bounds__(kThreads) void dense_lq_kernel(DenseView v, const S
     const double tau = sh_tau, scale = sh_scale;
     if (tau != 0.0) {
       // v = [1 ; scale * x]; rows j > c:  w = tau (T[j][c] + scale * Mt[j].x)
-      for (int j = c + 1 + wv; j < D; j += 4) {
+      for (int j = c + 1 + wv; j < rows_total; j += 4) {
         double* y = Mt + size_t(j) * D;
         double dot = 0.0;
         for (int q = lane; q < D; q += kWave) dot += y[q] * x[q];
@@ -249,7 +259,7 @@ __global__ __launch_bounds__(kThreads) void dense_correct_kernel(DenseView v, co
   double* red = wz + d;    // [4]
   double p[kMaxN], pinv[kMaxN];
   preconditioner_rt(n, arg.dt, K, p, pinv);
-  const double* T = v.R + size_t(b) * D * D;   // L^- in preconditioned coordinates (lower)
+  const double* T = v.R + size_t(b) * v.mr_rows * D * D;   // L^- in preconditioned coordinates (lower)
   const double* Jg = v.J + size_t(b) * d * kd;
   double* F = v.Ft + size_t(b) * d * D;        // F, then W  (d x D)
   double* Y = v.X + size_t(b) * D * d;         // Y = L^- W^T (D x d)
@@ -375,11 +385,15 @@ void dense_launch_step(const DenseView& v, const StepArg* args, const IwpConst* 
   const int rows_per = v.D < 64 ? v.D : 64;
   hipLaunchKernelGGL(dense_lq_input_kernel, dim3(rows_per, v.B), dim3(kThreads), 0, s, v, args, K);
   mark(2);
-  hipLaunchKernelGGL(dense_lq_kernel, dim3(v.B), dim3(kThreads), 0, s, v, args);
+  hipLaunchKernelGGL(dense_lq_kernel, dim3(v.B), dim3(kThreads), 0, s, v, v.fixedpoint ? 2 * v.D : v.D);
   mark(3);
   const size_t shm_corr = (size_t(v.d) + 4) * sizeof(double);
   hipLaunchKernelGGL(dense_correct_kernel, dim3(v.B), dim3(kThreads), shm_corr, s, v, args, K);
   mark(4);
+}
+
+void dense_launch_lq_generic(const DenseView& v, int rows_total, hipStream_t s) {
+  hipLaunchKernelGGL(dense_lq_kernel, dim3(v.B), dim3(kThreads), 0, s, v, rows_total);
 }
 
 void dense_launch_interp(const DenseView& v, const InterpArg* args, const IwpConst* K, hipStream_t s) {

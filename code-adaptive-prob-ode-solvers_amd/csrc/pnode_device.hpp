@@ -56,6 +56,16 @@ struct DenseView {
   double* X;     // [B][d][D]  W U^-
   double* S;     // [B][d][d]
   double* sig_new;  // [B]
+  // fixed-point smoother (dense): slots 0..2 rotate, 3..4 are interpolation temporaries
+  int fixedpoint, nslots, mr_rows;  // mr_rows: M and R hold mr_rows * D rows per trajectory (2 with fixedpoint)
+  int32_t* act;     // [B] activity flags of the running batched operation (written by the input kernels)
+  double* mext;     // [B][D] extrapolated mean of the running operation
+  double* cG;       // [nslots][B][D][D] backward transition  x_prev | x ~ N(G x + xi, Lam Lam^T)
+  double* cxi;      // [nslots][B][D]
+  double* cLam;     // [nslots][B][D][D] lower triangular
+  double* ck_G;     // [B][K][D][D]
+  double* ck_xi;    // [B][K][D]
+  double* ck_Lam;   // [B][K][D][D]
 };
 
 // Optional per-phase timing of one dense step: events[0..4] bracket begin | lq_input | lq | correct.
@@ -69,5 +79,11 @@ void dense_launch_mfma_begin(const DenseView& v, const StepArg* args, const IwpC
 void dense_launch_mfma_tail(const DenseView& v, const StepArg* args, const IwpConst* K, hipStream_t s,
                             const PhaseEvents* ev);
 void dense_launch_interp(const DenseView& v, const InterpArg* args, const IwpConst* K, hipStream_t s);
+// dense fixed-point smoother (generic kernels, pnode_dense_fp.hip)
+void dense_fp_launch_step_tail(const DenseView& v, const FpArg* fargs, const IwpConst* K, hipStream_t s);
+void dense_fp_launch_interp(const DenseView& v, const InterpArg* iargs, const FpArg* op1, const FpArg* op2, const IwpConst* K,
+                            hipStream_t s);
+void dense_fp_launch_smooth(const DenseView& v, const int32_t* num_filled, double* out, hipStream_t s);
+void dense_launch_lq_generic(const DenseView& v, int rows_total, hipStream_t s);
 
 }  // namespace pnode

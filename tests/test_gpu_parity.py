@@ -429,3 +429,30 @@ def test_device_resident_controller_matches_host_controller(hip_lib, golden):
     py = ivpsolve.solve_adaptive_save_at(vf, init, save_at=save_at, dt0=0.1, adaptive_solver=asolver, python_controller=True)
     assert np.array_equal(py.num_steps, host.num_steps)
     assert np.max(np.abs(py.u - host.u)) < 1e-10
+
+
+@pytest.mark.parametrize("case", ["brusselator4", "rigid", "vdp2"])
+def test_dense_fixedpoint_smoother_vs_oracle(hip_lib, case):
+    """strategy_fixedpoint with the dense model (BASELINE config 5's smoother, at test size): adaptive solve with
+    checkpoints; accepted steps, one-step-smoothed checkpoint values and fully smoothed means against the oracle."""
+    if case == "brusselator4":
+        vf, nu, corr, u0s, tol, save_at, dt0 = V.brusselator(4), 3, "ts1", [brusselator_y0(4)], 1e-5, np.linspace(0, 1.0, 6), 0.01
+    elif case == "rigid":
+        vf, nu, corr, u0s, tol, save_at, dt0 = V.rigid_body(), 2, "ts1", [np.array([1.0, 0.0, 0.9])], 1e-4, np.linspace(0, 4.0, 5), 0.1
+    else:
+        vf, nu, corr, u0s, tol, save_at, dt0 = (V.van_der_pol_order2(5.0), 4, "ts1", [np.array([2.0]), np.array([0.0])], 1e-4,
+                                               np.linspace(0, 2.0, 5), 0.01)
+    impl.select("dense", ode_shape=(vf.d,))
+    correction = ivpsolvers.correction_ts1(ode_order=vf.ode_order)
+    solver = ivpsolvers.solver_dynamic(ivpsolvers.strategy_fixedpoint(ivpsolvers.prior_ibm(nu), correction))
+    tcs = tcoeffs(vf, u0s, nu)
+    init = solver.initial_condition(tcs, 1.0)
+    sol = ivpsolve.solve_adaptive_save_at(vf, init, save_at=save_at, dt0=dt0, adaptive_solver=ivpsolve.adaptive(solver, atol=tol, rtol=tol))
+    cfg = po.SolverConfig(nu=nu, model="dense", correction=corr, strategy="fixedpoint", calibration="dynamic")
+    osol = po.solve_adaptive_save_at(cfg, po.AdaptiveConfig(tol, tol), oracle_problem(vf), po.initial_state(cfg, tcs, 0.0), save_at, dt0)
+    assert np.array_equal(sol.num_steps, osol.num_steps)
+    ck = sol.posterior.batch.read_checkpoint_means()[0]
+    assert relmax(ck[:, 0], osol.u[1:]) < 1e-9           # one-step-smoothed interpolants
+    sm = po.markov_marginals_reverse(cfg, osol)
+    assert relmax(sol.u, sm[:, 0]) < 1e-8                 # backward pass over the stored transitions
+    assert relmax(sol.posterior.means[0, :, 1], sm[:, 1]) < 1e-6
