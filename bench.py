@@ -78,6 +78,8 @@ def cpu_baseline(seconds=15.0):
         threads = len(os.sched_getaffinity(0))
     except AttributeError:
         threads = os.cpu_count() or 1
+    # a 1-GPU box grants a CPU share of 16 cores whatever the affinity mask says; more threads only contend
+    threads = int(os.environ.get("PNODE_CPU_THREADS", min(threads, 16)))
     vf, tcs = problem_batch(threads, 0, 1024)
     tc = np.ascontiguousarray(np.stack(tcs, axis=1))
     path = os.path.join(ROOT, "oracle", "libpn_oracle_c.so")
