@@ -62,10 +62,11 @@ def measured_traffic(kernel_prefix, batch):
         data = json.load(open(path))
     except OSError:
         return None
-    for name, v in data.items():
+    total = 0.0
+    for name, v in data.items():  # the LQ runs as two launches (first pass + remaining passes): sum them
         if name.startswith(kernel_prefix) and "hbm_bytes_per_launch" in v:
-            return v["hbm_bytes_per_launch"] * batch / 1024.0  # the profile run uses 1024 trajectories
-    return None
+            total += v["hbm_bytes_per_launch"]
+    return total * batch / 1024.0 if total > 0.0 else None  # the profile run uses 1024 trajectories
 
 
 def cpu_baseline(seconds=15.0):
@@ -246,7 +247,8 @@ def main():
             out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": achieved / FP64_PEAK_TFLOPS, "traffic": measured_traffic("dense_lq2_mfma_kernel", B),
                                "traffic_source": "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
-                               "kernel": "dense_lq2_mfma_kernel<16>", "algorithmic_flops_per_launch": flops,
+                               "kernel": "dense_lq2_mfma_kernel<16,true> + <16,false> (one LQ, two launches)",
+                               "algorithmic_flops_per_launch": flops,
                                "phase_ms": {"begin": phase[0] / K, "lq_input": phase[1] / K, "lq": phase[2] / K,
                                             "correct": phase[3] / K}}
         else:
