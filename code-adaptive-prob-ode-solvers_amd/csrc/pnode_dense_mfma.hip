@@ -100,6 +100,9 @@ template <int DT, int LDV>
 __device__ __forceinline__ void factor_panel(double* rows, const PanelScratch& ps, double* Gm, double* Nm, double t0diag,
                                              int tid, int ablate) {
   const int rr = tid >> 4, ch = tid & 15;
+  // the sweep is a chain of dependent short instructions: give it issue priority over the co-resident
+  // workgroup's MFMA stream (which only needs one issue slot per 64 cycles)
+  __builtin_amdgcn_s_setprio(3);
   ps.Tpp[tid] = (rr == ch) ? t0diag : 0.0;
   Gm[tid] = 0.0;
   // each 16-lane group keeps ITS row in registers for the whole sweep; a row is published to LDS
@@ -186,6 +189,7 @@ __device__ __forceinline__ void factor_panel(double* rows, const PanelScratch& p
     __syncthreads();
     A[tid] = tf;
   }
+  __builtin_amdgcn_s_setprio(0);
   __syncthreads();
 }
 
