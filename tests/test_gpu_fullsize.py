@@ -120,3 +120,19 @@ def test_isotropic_full_batch_contains_the_reference_trajectory(hip_lib, golden)
     assert np.max(np.abs(sol.u)) < 10.0
     # step counts vary smoothly over the family
     assert sol.num_steps[:, -1].min() > 5000 and sol.num_steps[:, -1].max() < 30000
+
+
+def test_brusselator_n128_three_quarters_of_a_million_decisions(hip_lib, golden):
+    """Reference experiment 4 at N = 128 (d = 256, the ODE size of BASELINE config 5), device-resident controller:
+    190 024 accepted steps, bit-exact with the committed JAX result; smoothed means within 1e-9."""
+    g = golden["brusselator"]
+    Nn = 128
+    vf = V.brusselator(Nn)
+    impl.select("isotropic", ode_shape=(2 * Nn,))
+    solver = ivpsolvers.solver_dynamic(ivpsolvers.strategy_fixedpoint(ivpsolvers.prior_ibm(4), ivpsolvers.correction_ts0()))
+    tcs = taylor.odejet_unroll(vf, [brusselator_y0(Nn)], num=4)
+    sol = ivpsolve.solve_adaptive_save_at(vf, solver.initial_condition(tcs, 1.0), save_at=g["ts"], dt0=0.01,
+                                          adaptive_solver=ivpsolve.adaptive(solver, atol=1e-8, rtol=1e-8), device_controller=True)
+    i = list(g["N"]).index(Nn)
+    assert int(np.max(sol.num_steps)) == int(g["num_steps_checkpoint"][i]) == 190024
+    assert np.max(np.abs(sol.u - g["ys_N128"])) < 1e-9
