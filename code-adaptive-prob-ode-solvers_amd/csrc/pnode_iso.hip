@@ -202,11 +202,30 @@ __device__ __forceinline__ void store_small(double* __restrict__ dst, const doub
 // The fused attempted step
 // ---------------------------------------------------------------------------------------------
 
-// One attempted step of trajectory b by one wavefront: reads slot arg.src, writes slot arg.dst, returns the
-// normalised error norm (wave-uniform). ybuf [k][d] and zbuf [d] are this wave's LDS scratch.
-template <int N, bool FP>
+// Sum over the W wavefronts that share a trajectory (W = 1: plain wave reduction).
+template <int W>
+__device__ __forceinline__ double team_sum(double v, double* red, int wteam) {
+  v = wave_sum(v);
+  if constexpr (W == 1) return v;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[wteam] = v;
+  __syncthreads();
+  double t = 0.0;
+#pragma unroll
+  for (int i = 0; i < W; ++i) t += red[i];
+  return t;
+}
+
+// One attempted step of trajectory b by a team of W wavefronts (W = 1: one wave per trajectory, four
+// trajectories per workgroup; W = 4: the whole 256-thread workgroup works on one trajectory, used for large d):
+// reads slot arg.src, writes slot arg.dst, returns the normalised error norm (team-uniform). `lane` is the
+// index inside the team (0 .. 64 W - 1); ybuf [k][d], zbuf [d], red [W] are the team's LDS scratch. The n x n
+// algebra is computed redundantly by every lane (no communication).
+template <int N, bool FP, int W>
 __device__ __forceinline__ double iso_attempt(const IsoView& v, const IwpConst& K, int b, int lane, const StepArg& arg,
-                                              double* ybuf, double* zbuf) {
+                                              double* ybuf, double* zbuf, double* red) {
+  constexpr int kTeam = kWave * W;
+  const int wteam = lane >> 6;
   const int d = v.d, k = v.k;
 
   const double dt = arg.dt;
@@ -218,7 +237,7 @@ __device__ __forceinline__ double iso_attempt(const IsoView& v, const IwpConst& 
   double* mdst = v.mean + (size_t(arg.dst) * sB + b) * N * d;
 
   // --- pass A: mean extrapolation  m^- = P Abar P^{-1} m
-  for (int j = lane; j < d; j += kWave) {
+  for (int j = lane; j < d; j += kTeam) {
     double mp[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) mp[i] = pinv[i] * msrc[i * d + j];
@@ -232,20 +251,24 @@ __device__ __forceinline__ double iso_attempt(const IsoView& v, const IwpConst& 
       if (i < k) ybuf[i * d + j] = e;
     }
   }
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_s_waitcnt(0);  // LDS writes of this wave visible to all its lanes
+  if constexpr (W == 1) {
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0);  // LDS writes of this wave visible to all its lanes
+  } else {
+    __syncthreads();
+  }
 
   // --- pass B: residual z = m^-[k] - f(m^-[<k])  and its norm
   VfCtx ctx{v.vf_id, d, k, v.prm ? v.prm + (v.prm_per_traj ? size_t(b) * v.P : 0) : nullptr};
   const double tnew = arg.t + dt;
   double zz = 0.0;
-  for (int j = lane; j < d; j += kWave) {
+  for (int j = lane; j < d; j += kTeam) {
     const double z = mdst[k * d + j] - vf_f(ctx, ybuf, j, tnew);
     zbuf[j] = z;
     zz += z * z;
   }
-  zz = wave_sum(zz);
+  zz = team_sum<W>(zz, red, wteam);
 
   // --- calibration + error estimate (isotropic EKF0: S1 = s1^2, s1 = p_k * sqrt(Qbar_kk))
   const double s1 = p[k] * K.qdiag_sqrt[k];
@@ -266,7 +289,7 @@ __device__ __forceinline__ double iso_attempt(const IsoView& v, const IwpConst& 
     load_small<N>(v.cLam + (size_t(arg.src) * sB + b) * N * N, RL0);
     const double* xi0 = v.cxi + (size_t(arg.src) * sB + b) * N * d;
     double* xid = v.cxi + (size_t(arg.dst) * sB + b) * N * d;
-    for (int j = lane; j < d; j += kWave) {
+    for (int j = lane; j < d; j += kTeam) {
       double xi[N], me[N];
 #pragma unroll
       for (int i = 0; i < N; ++i) me[i] = mdst[i * d + j];
@@ -314,7 +337,7 @@ __device__ __forceinline__ double iso_attempt(const IsoView& v, const IwpConst& 
   // --- pass C: corrected mean + normalised error norm
   const double atol = v.atol[b], rtol = v.rtol[b];
   double acc2 = 0.0;
-  for (int j = lane; j < d; j += kWave) {
+  for (int j = lane; j < d; j += kTeam) {
     const double z = zbuf[j];
     double u0 = 0.0;
 #pragma unroll
@@ -326,24 +349,26 @@ __device__ __forceinline__ double iso_attempt(const IsoView& v, const IwpConst& 
     const double rel = err / (atol + rtol * fabs(u0));
     acc2 += rel * rel;
   }
-  acc2 = wave_sum(acc2);
+  acc2 = team_sum<W>(acc2, red, wteam);
   if (lane == 0) v.sigma[size_t(arg.dst) * sB + b] = sigma;
   return sqrt(acc2 / double(d));
 }
 
-template <int N, bool FP>
+template <int N, bool FP, int W>
 __global__ __launch_bounds__(256) void iso_step_kernel(IsoView v, const StepArg* __restrict__ args,
                                                        const IwpConst* __restrict__ Kc) {
   extern __shared__ double smem[];
-  const int lane = threadIdx.x & 63;
-  const int wv = threadIdx.x >> 6;
-  const int b = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv);
+  constexpr int TPB = 4 / W;  // trajectories per 256-thread workgroup
+  const int lane = threadIdx.x % (kWave * W);
+  const int team = threadIdx.x / (kWave * W);
+  const int b = __builtin_amdgcn_readfirstlane(blockIdx.x * TPB + team);
   if (b >= v.B) return;
   const StepArg arg = args[b];
   if (!arg.active) return;
-  double* ybuf = smem + size_t(wv) * (size_t(v.k) + 1) * v.d;  // [k][d] staged state for the vector field
-  double* zbuf = ybuf + size_t(v.k) * v.d;                     // [d] residual
-  const double e = iso_attempt<N, FP>(v, *Kc, b, lane, arg, ybuf, zbuf);
+  double* ybuf = smem + size_t(team) * ((size_t(v.k) + 1) * v.d + 4);  // [k][d] staged state for the vector field
+  double* zbuf = ybuf + size_t(v.k) * v.d;                            // [d] residual
+  double* red = zbuf + v.d;                                           // [W]
+  const double e = iso_attempt<N, FP, W>(v, *Kc, b, lane, arg, ybuf, zbuf, red);
   if (lane == 0) v.errnorm[b] = e;
 }
 
@@ -351,18 +376,20 @@ __global__ __launch_bounds__(256) void iso_step_kernel(IsoView v, const StepArg*
 // step-size law for ITS trajectory until the next save_at point is reached (or an iteration budget is spent), so
 // the host synchronises once per checkpoint interval instead of once per attempted step. Same arithmetic as the
 // host controller in pnode_solve_adaptive_save_at.
-template <int N, bool FP>
+template <int N, bool FP, int W>
 __global__ __launch_bounds__(256) void iso_advance_kernel(IsoView v, TrajCtl* __restrict__ ctl, const IwpConst* __restrict__ Kc,
                                                           ControlParams cp) {
   extern __shared__ double smem[];
-  const int lane = threadIdx.x & 63;
-  const int wv = threadIdx.x >> 6;
-  const int b = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv);
+  constexpr int TPB = 4 / W;
+  const int lane = threadIdx.x % (kWave * W);
+  const int team = threadIdx.x / (kWave * W);
+  const int b = __builtin_amdgcn_readfirstlane(blockIdx.x * TPB + team);
   if (b >= v.B) return;
   TrajCtl c = ctl[b];
   if (c.status < 0) return;
-  double* ybuf = smem + size_t(wv) * (size_t(v.k) + 1) * v.d;
+  double* ybuf = smem + size_t(team) * ((size_t(v.k) + 1) * v.d + 4);
   double* zbuf = ybuf + size_t(v.k) * v.d;
+  double* red = zbuf + v.d;
   int iters = 0;
   c.status = 0;
   while (c.t_sf + cp.numerical_zero < c.t_stop && iters < cp.max_iters) {
@@ -370,8 +397,9 @@ __global__ __launch_bounds__(256) void iso_advance_kernel(IsoView v, TrajCtl* __
     if (cp.clip) dt = fmin(dt, c.t_stop - c.t_sf);
     StepArg arg;
     arg.dt = dt; arg.t = c.t_sf; arg.src = c.s_sf; arg.dst = c.s_pr; arg.active = 1; arg.pad = 0;
-    const double e = iso_attempt<N, FP>(v, *Kc, b, lane, arg, ybuf, zbuf);
-    __threadfence_block();  // the slot written by this attempt is read by the next one (other lanes of this wave)
+    const double e = iso_attempt<N, FP, W>(v, *Kc, b, lane, arg, ybuf, zbuf, red);
+    if constexpr (W > 1) __syncthreads();
+    __threadfence_block();  // the slot written by this attempt is read by the next one (other lanes of the team)
     ++iters;
     c.attempts += 1;
     bool accept;
@@ -655,14 +683,25 @@ __global__ __launch_bounds__(256) void iso_smooth_kernel(IsoView v, const int32_
 // Host-side launchers (dispatch on n = nu + 1 and strategy)
 // ---------------------------------------------------------------------------------------------
 
+// one wave per trajectory up to d = 128; the whole workgroup on one trajectory beyond (latency of a step
+// falls ~3x for d >= 256, which is what a single long trajectory is bound by)
+static inline bool iso_wide(const IsoView& v) { return v.d > 128; }
+static inline size_t iso_shm(const IsoView& v, int tpb) { return size_t(tpb) * ((size_t(v.k) + 1) * v.d + 4) * sizeof(double); }
+
 template <int N>
 static void launch_step_n(const IsoView& v, const StepArg* args, const IwpConst* K, hipStream_t s) {
+  if (iso_wide(v)) {
+    if (v.fixedpoint)
+      hipLaunchKernelGGL((iso_step_kernel<N, true, 4>), dim3(v.B), dim3(256), iso_shm(v, 1), s, v, args, K);
+    else
+      hipLaunchKernelGGL((iso_step_kernel<N, false, 4>), dim3(v.B), dim3(256), iso_shm(v, 1), s, v, args, K);
+    return;
+  }
   const int blocks = (v.B + 3) / 4;
-  const size_t shm = size_t(4) * (size_t(v.k) + 1) * v.d * sizeof(double);
   if (v.fixedpoint)
-    hipLaunchKernelGGL((iso_step_kernel<N, true>), dim3(blocks), dim3(256), shm, s, v, args, K);
+    hipLaunchKernelGGL((iso_step_kernel<N, true, 1>), dim3(blocks), dim3(256), iso_shm(v, 4), s, v, args, K);
   else
-    hipLaunchKernelGGL((iso_step_kernel<N, false>), dim3(blocks), dim3(256), shm, s, v, args, K);
+    hipLaunchKernelGGL((iso_step_kernel<N, false, 1>), dim3(blocks), dim3(256), iso_shm(v, 4), s, v, args, K);
 }
 template <int N>
 static void launch_interp_n(const IsoView& v, const InterpArg* args, const IwpConst* K, hipStream_t s) {
@@ -698,12 +737,18 @@ void iso_launch_interp(const IsoView& v, const InterpArg* args, const IwpConst* 
 }
 template <int N>
 static void launch_advance_n(const IsoView& v, TrajCtl* ctl, const IwpConst* K, const ControlParams& cp, hipStream_t s) {
+  if (iso_wide(v)) {
+    if (v.fixedpoint)
+      hipLaunchKernelGGL((iso_advance_kernel<N, true, 4>), dim3(v.B), dim3(256), iso_shm(v, 1), s, v, ctl, K, cp);
+    else
+      hipLaunchKernelGGL((iso_advance_kernel<N, false, 4>), dim3(v.B), dim3(256), iso_shm(v, 1), s, v, ctl, K, cp);
+    return;
+  }
   const int blocks = (v.B + 3) / 4;
-  const size_t shm = size_t(4) * (size_t(v.k) + 1) * v.d * sizeof(double);
   if (v.fixedpoint)
-    hipLaunchKernelGGL((iso_advance_kernel<N, true>), dim3(blocks), dim3(256), shm, s, v, ctl, K, cp);
+    hipLaunchKernelGGL((iso_advance_kernel<N, true, 1>), dim3(blocks), dim3(256), iso_shm(v, 4), s, v, ctl, K, cp);
   else
-    hipLaunchKernelGGL((iso_advance_kernel<N, false>), dim3(blocks), dim3(256), shm, s, v, ctl, K, cp);
+    hipLaunchKernelGGL((iso_advance_kernel<N, false, 1>), dim3(blocks), dim3(256), iso_shm(v, 4), s, v, ctl, K, cp);
 }
 void iso_launch_advance(const IsoView& v, TrajCtl* ctl, const IwpConst* K, const ControlParams& cp, hipStream_t s) {
 #define CALL(NN) launch_advance_n<NN>(v, ctl, K, cp, s)
