@@ -85,6 +85,24 @@ __device__ __forceinline__ void preconditioner(double dt, const IwpConst& K, dou
   }
 }
 
+// 1/sqrt(x) and 1/x to full fp64 precision from the hardware estimates + Newton steps: short dependency chains
+// instead of the ~30-instruction IEEE sqrt / divide expansions (the small-matrix algebra is latency-bound).
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const double e = fma(-x * y, y, 1.0);  // 1 - x y^2
+    y = fma(0.5 * y, e, y);
+  }
+  return y;
+}
+__device__ __forceinline__ double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) y = fma(fma(-x, y, 1.0), y, y);
+  return y;
+}
+
 // Rotate the row x (length N) into the upper-triangular R (N x N) with Givens rotations:
 // afterwards R^T R (new) = R^T R (old) + x^T x. Orthogonal transformations only.
 template <int N>
@@ -94,9 +112,10 @@ __device__ __forceinline__ void givens_rotate_in(double (&R)[N][N], double (&x)[
     const double xj = x[j];
     if (xj != 0.0) {
       const double rjj = R[j][j];
-      const double r = sqrt(rjj * rjj + xj * xj);
-      const double c = rjj / r, s = xj / r;
-      R[j][j] = r;
+      const double h2 = fma(rjj, rjj, xj * xj);
+      const double inv = fast_rsqrt(h2);
+      const double c = rjj * inv, s = xj * inv;
+      R[j][j] = h2 * inv;
 #pragma unroll
       for (int l = j + 1; l < N; ++l) {
         const double rl = R[j][l], xl = x[l];

@@ -73,24 +73,6 @@ struct PanelScratch {
   double* beta;   // [16]
 };
 
-// 1/sqrt(x) and 1/x to full fp64 precision from the hardware estimates + Newton steps (no division
-// sequences on the critical path of the panel sweep).
-__device__ __forceinline__ double fast_rsqrt(double x) {
-  double y = __builtin_amdgcn_rsq(x);
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const double e = fma(-x * y, y, 1.0);     // 1 - x y^2
-    y = fma(0.5 * y, e, y);
-  }
-  return y;
-}
-__device__ __forceinline__ double fast_rcp(double x) {
-  double y = __builtin_amdgcn_rcp(x);
-#pragma unroll
-  for (int i = 0; i < 2; ++i) y = fma(fma(-x, y, 1.0), y, y);
-  return y;
-}
-
 // Row-Householder factorisation of the 16 LDS rows starting at `rows` (stride LDV); one barrier per
 // row. Groups above the pivot row (idle in a textbook sweep) compute the Gram entries the T-factor
 // needs. The rows are left UNSCALED: reflector c is v_c = [1 ; scl[c] * rows[c]]; consumers scale

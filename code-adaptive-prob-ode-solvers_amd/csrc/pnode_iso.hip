@@ -57,6 +57,9 @@ __device__ __forceinline__ void iso_time_update(const IwpConst& K, const double 
   if constexpr (COND) {
     // cross = Sigma~ Abar^T = Bm^T M ;  Gp = cross (R^T R)^{-1}
     double Gp[N][N];
+    double rinv[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) rinv[j] = (R[j][j] != 0.0) ? fast_rcp(R[j][j]) : 0.0;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       double row[N];
@@ -67,13 +70,13 @@ __device__ __forceinline__ void iso_time_update(const IwpConst& K, const double 
         for (int c = 0; c < N; ++c) acc += Bm[c][i] * M[c][j];
         row[j] = acc;
       }
-      // y R = row  (R upper: forward over columns)
+      // y R = row  (R upper: forward over columns); rinv: reciprocal pivots, 0 on an exactly singular factor
 #pragma unroll
       for (int j = 0; j < N; ++j) {
         double acc = row[j];
 #pragma unroll
         for (int k = 0; k < j; ++k) acc -= row[k] * R[k][j];
-        row[j] = (R[j][j] != 0.0) ? acc / R[j][j] : 0.0;  // pseudo-inverse on an exactly singular factor
+        row[j] = acc * rinv[j];
       }
       // x R^T = y  (backward)
 #pragma unroll
@@ -81,7 +84,7 @@ __device__ __forceinline__ void iso_time_update(const IwpConst& K, const double 
         double acc = row[j];
 #pragma unroll
         for (int k = j + 1; k < N; ++k) acc -= row[k] * R[j][k];
-        row[j] = (R[j][j] != 0.0) ? acc / R[j][j] : 0.0;
+        row[j] = acc * rinv[j];
       }
 #pragma unroll
       for (int j = 0; j < N; ++j) Gp[i][j] = row[j];
