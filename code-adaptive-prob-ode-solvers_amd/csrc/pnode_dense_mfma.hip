@@ -439,8 +439,8 @@ __device__ __forceinline__ void lds_cholesky_blocked(double* Sm, int tid) {
       for (int c = 0; c < 16; ++c) {
         const double piv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a[c]), c),
                                             __builtin_amdgcn_readlane(__double2loint(a[c]), c));
-        const double sq = sqrt(piv);
-        a[c] = (r == c) ? sq : a[c] / sq;
+        const double rs = fast_rsqrt(piv);  // NaN for a non-positive pivot, like sqrt
+        a[c] = (r == c) ? piv * rs : a[c] * rs;
 #pragma unroll
         for (int q = c + 1; q < 16; ++q) {
           const double lq = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a[c]), q),
@@ -465,7 +465,7 @@ __device__ __forceinline__ void lds_cholesky_blocked(double* Sm, int tid) {
         double acc = x[c];
 #pragma unroll
         for (int m = 0; m < c; ++m) acc -= x[m] * Sm[(o + c) * LD + o + m];
-        x[c] = acc / Sm[(o + c) * LD + o + c];
+        x[c] = acc * fast_rcp(Sm[(o + c) * LD + o + c]);
       }
 #pragma unroll
       for (int j = 0; j < 16; ++j) Sm[row * LD + o + j] = x[j];
