@@ -13,6 +13,13 @@ for p in (PKG, os.path.join(ROOT, "oracle"), os.path.dirname(os.path.abspath(__f
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the shared libraries are build artefacts (git-ignored): build them once if a fresh checkout lacks them
+    need = [os.path.join(PKG, "csrc", "libpnode_hip.so"), os.path.join(ROOT, "oracle", "libpn_oracle_c.so")]
+    if not all(os.path.exists(p) for p in need):
+        sys.path.insert(0, ROOT)
+        import __graft_entry__
+
+        __graft_entry__.build()
 
 
 @pytest.fixture(scope="session")

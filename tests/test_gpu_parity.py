@@ -456,3 +456,60 @@ def test_dense_fixedpoint_smoother_vs_oracle(hip_lib, case):
     sm = po.markov_marginals_reverse(cfg, osol)
     assert relmax(sol.u, sm[:, 0]) < 1e-8                 # backward pass over the stored transitions
     assert relmax(sol.posterior.means[0, :, 1], sm[:, 1]) < 1e-6
+
+
+@pytest.mark.parametrize("model", ["isotropic", "dense"])
+def test_uncalibrated_solver_matches_oracle(hip_lib, model):
+    """ivpsolvers.solver(strategy) (calibrate="none", ivpsolvers.py:47-48): fixed output scale in the covariance,
+    locally calibrated error estimate; adaptive solve against the oracle, two output scales in one batch."""
+    vf = V.rigid_body()
+    scales = np.array([1.0, 25.0])
+    B = 2
+    impl.select(model, ode_shape=(3,))
+    corr = ivpsolvers.correction_ts0() if model == "isotropic" else ivpsolvers.correction_ts1()
+    strat = ivpsolvers.strategy_fixedpoint if model == "isotropic" else ivpsolvers.strategy_filter
+    solver = ivpsolvers.solver(strat(ivpsolvers.prior_ibm(3), corr))
+    u0 = np.tile(np.array([1.0, 0.0, 0.9]), (B, 1))
+    tcs = tcoeffs(vf, [u0], 3)
+    init = solver.initial_condition(tcs, output_scale=scales)
+    save_at = np.linspace(0.0, 5.0, 6)
+    sol = ivpsolve.solve_adaptive_save_at(vf, init, save_at=save_at, dt0=0.1, adaptive_solver=ivpsolve.adaptive(solver, atol=1e-6, rtol=1e-4))
+    assert np.allclose(sol.output_scale, scales)
+    cfg = po.SolverConfig(nu=3, model=model, correction="ts0" if model == "isotropic" else "ts1",
+                          strategy="fixedpoint" if model == "isotropic" else "filter", calibration="none")
+    for b in range(B):
+        osol = po.solve_adaptive_save_at(cfg, po.AdaptiveConfig(1e-6, 1e-4), oracle_problem(vf),
+                                         po.initial_state(cfg, [c[b] for c in tcs], 0.0, scales[b]), save_at, 0.1)
+        ref = po.markov_marginals_reverse(cfg, osol)[:, 0] if model == "isotropic" else osol.u
+        assert np.array_equal(sol.num_steps[b], osol.num_steps)
+        assert relmax(sol.u[b], ref) < 1e-9
+    # the covariance scales with output_scale^2 while the means of the filter do not depend on it
+    R = sol.posterior.batch.read_factor(0)
+    cov0, cov1 = R[0].T @ R[0], R[1].T @ R[1]
+    if model == "dense":
+        assert relmax(cov1, cov0 * (scales[1] / scales[0]) ** 2) < 1e-6
+
+
+def test_edge_cases_single_checkpoint_ragged_save_at_and_nan_propagation(hip_lib):
+    """B = 1 with one checkpoint; per-trajectory (ragged) save_at grids; a trajectory whose vector field blows up
+    must come back as NaN/flagged without disturbing its batch neighbours (the reference propagates NaNs,
+    vdp.py:107-108, it never traps them)."""
+    vf = V.logistic(1.0, 1.0)
+    impl.select("isotropic", ode_shape=(1,))
+    solver = ivpsolvers.solver_dynamic(ivpsolvers.strategy_filter(ivpsolvers.prior_ibm(2), ivpsolvers.correction_ts0()))
+    init = solver.initial_condition(tcoeffs(vf, [np.array([0.1])], 2), 1.0)
+    sol = ivpsolve.solve_adaptive_save_at(vf, init, save_at=np.array([0.0, 1.0]), dt0=0.1, adaptive_solver=ivpsolve.adaptive(solver, atol=1e-6, rtol=1e-6))
+    exact = 0.1 * np.exp(1.0) / (1.0 + 0.1 * (np.exp(1.0) - 1.0))
+    assert sol.u.shape == (2, 1) and abs(sol.u[-1, 0] - exact) < 1e-4
+    # ragged grids + a diverging member: u' = u (1 - b u) with b < 0 blows up in finite time
+    vfb = V.VectorField(V.VF_LOGISTIC, 1, 1, np.array([[1.0, 1.0], [1.0, -5.0], [1.0, 1.0]]), "logistic")
+    u0 = np.array([[0.1], [1.0], [0.3]])
+    tcs = [u0, u0 * (1 - np.array([[1.0], [-5.0], [1.0]]) * u0)]
+    tcs.append(tcs[1] * (1 - 2 * np.array([[1.0], [-5.0], [1.0]]) * u0))
+    init = solver.initial_condition(tcs, 1.0)
+    save_at = np.stack([np.linspace(0.0, 2.0, 4), np.linspace(0.0, 1.0, 4), np.linspace(0.0, 3.0, 4)])
+    sol = ivpsolve.solve_adaptive_save_at(vfb, init, save_at=save_at, dt0=0.05, adaptive_solver=ivpsolve.adaptive(solver, atol=1e-8, rtol=1e-6))
+    ex = lambda u, t: u * np.exp(t) / (1.0 + u * (np.exp(t) - 1.0))  # noqa: E731
+    assert abs(sol.u[0, -1, 0] - ex(0.1, 2.0)) < 1e-4 and abs(sol.u[2, -1, 0] - ex(0.3, 3.0)) < 1e-4
+    # the diverging member (blow-up at t = log(6/5) ~ 0.18) never reaches its later checkpoints
+    assert not np.all(np.isfinite(sol.u[1])) or sol.num_steps[1, -1] == 0 or np.max(np.abs(sol.u[1])) > 1e3
