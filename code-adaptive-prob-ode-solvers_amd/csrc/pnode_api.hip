@@ -76,6 +76,26 @@ void fill_iwp(int nu, IwpConst* K) {
   }
 }
 
+// m^-[i][j] = (P Abar P^-1 m)[i][j] for i < k: what a host-evaluated vector field needs before an attempt.
+__global__ void user_extrapolate_kernel(const double* __restrict__ mean, const StepArg* __restrict__ args,
+                                        const IwpConst* __restrict__ Kc, double* __restrict__ y, int B, int n, int d, int k) {
+  const int b = blockIdx.x;
+  const StepArg a = args[b];
+  if (!a.active) return;
+  const IwpConst& K = *Kc;
+  const double adt = fabs(a.dt);
+  double p[kMaxN], pinv[kMaxN];
+  double pw = sqrt(adt);
+  for (int i = n - 1; i >= 0; --i) { p[i] = pw / K.fact[i]; pinv[i] = K.fact[i] / pw; pw *= adt; }
+  const double* m = mean + (size_t(a.src) * B + b) * n * d;
+  for (int j = threadIdx.x; j < d; j += blockDim.x)
+    for (int i = 0; i < k; ++i) {
+      double acc = 0.0;
+      for (int kk = i; kk < n; ++kk) acc += K.a[i][kk] * pinv[kk] * m[kk * d + j];
+      y[(size_t(b) * k + i) * d + j] = p[i] * acc;
+    }
+}
+
 __global__ void gather_u_kernel(const double* __restrict__ mean, const StepArg* __restrict__ args, double* __restrict__ out,
                                 int B, int n, int d, int G, int g) {
   const int b = blockIdx.x;
@@ -100,6 +120,7 @@ struct pnode_batch {
   InterpArg* dIargs = nullptr;
   int32_t* dFilled = nullptr;
   double *dAtol = nullptr, *dRtol = nullptr, *dPrm = nullptr, *dErr = nullptr;
+  double *dUserF = nullptr, *dUserJ = nullptr, *dUserY = nullptr;  // PNODE_VF_USER exchange buffers
   FpArg *hFp0 = nullptr, *hFp1 = nullptr, *zFp0 = nullptr, *zFp1 = nullptr;  // pinned + device views (dense fixedpoint)
   InterpArg* zIargs = nullptr;
   StepArg* zArgs = nullptr;     // device view of hArgs (zero-copy: kernels read the per-step arguments over PCIe)
@@ -187,6 +208,7 @@ int pnode_create(const pnode_config* cfg, pnode_batch** out) {
     case PNODE_VF_PLEIADES_ORDER1: rc = need(d == 28 && k == 1, "pleiades (order 1): d=28"); break;
     case PNODE_VF_LOGISTIC: rc = need(k == 1 && cfg->num_vf_params == 2, "logistic: order 1, params [a,b]"); break;
     case PNODE_VF_LINEAR: rc = need(k == 1 && cfg->num_vf_params == 1, "linear: order 1, params [lam]"); break;
+    case PNODE_VF_USER: rc = need(cfg->num_vf_params == 0, "user vector field: no device parameters"); break;
     default: rc = fail(PNODE_EINVAL, "unknown vf_id");
   }
   if (rc != PNODE_OK) return rc;
@@ -226,6 +248,11 @@ int pnode_create(const pnode_config* cfg, pnode_batch** out) {
   const size_t nprm = size_t(cfg->num_vf_params) * (cfg->vf_params_per_trajectory ? B : 1);
   ALLOC(h->dPrm, nprm);
   if (nprm) HIP_TRY(hipMemcpy(h->dPrm, cfg->vf_params, nprm * sizeof(double), hipMemcpyHostToDevice));
+  if (cfg->vf_id == PNODE_VF_USER) {
+    ALLOC(h->dUserF, B * size_t(d));
+    ALLOC(h->dUserJ, B * size_t(d) * k * d);
+    ALLOC(h->dUserY, B * size_t(k) * d);
+  }
   IwpConst hk;
   fill_iwp(cfg->nu, &hk);
   HIP_TRY(hipMemcpy(h->dK, &hk, sizeof(hk), hipMemcpyHostToDevice));
@@ -251,6 +278,7 @@ int pnode_create(const pnode_config* cfg, pnode_batch** out) {
       ALLOC(v.ck_Lam, B * Kc * n * n);
     }
     v.atol = h->dAtol; v.rtol = h->dRtol; v.prm = nprm ? h->dPrm : nullptr; v.errnorm = h->zErr;
+    v.user_f = h->dUserF; v.user_J = h->dUserJ;
   } else {
     DenseView& v = h->dn;
     v.B = int(B); v.d = d; v.k = k; v.n = int(n); v.D = int(D); v.K = int(Kc);
@@ -288,6 +316,7 @@ int pnode_create(const pnode_config* cfg, pnode_batch** out) {
     ALLOC(v.S, B * d * d);
     ALLOC(v.sig_new, B);
     v.atol = h->dAtol; v.rtol = h->dRtol; v.prm = nprm ? h->dPrm : nullptr; v.errnorm = h->zErr;
+    v.user_f = h->dUserF; v.user_J = h->dUserJ;
   }
   h->t_sf.assign(B, 0.0);
   h->t_if.assign(B, 0.0);
@@ -406,6 +435,40 @@ int pnode_attempt_step(pnode_batch* h, const double* dt, const uint8_t* active, 
   return PNODE_OK;
 }
 
+int pnode_user_extrapolate(pnode_batch* h, const double* dt, const uint8_t* active, double* y_out) {
+  if (!h || !dt || !active || !y_out) return fail(PNODE_EINVAL, "null argument");
+  if (h->cfg.vf_id != PNODE_VF_USER) return fail(PNODE_ESTATE, "pnode_user_extrapolate needs vf_id = PNODE_VF_USER");
+  if (!h->initialised) return fail(PNODE_ESTATE, "set_initial has not been called");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  const size_t B = h->cfg.batch, d = h->cfg.d, k = h->cfg.ode_order;
+  for (size_t b = 0; b < B; ++b) {
+    StepArg& a = h->hArgs[b];
+    a.dt = dt[b]; a.t = h->t_sf[b]; a.src = h->s_sf[b]; a.dst = h->s_pr[b]; a.active = active[b] ? 1 : 0; a.pad = 0;
+    if (active[b] && !(dt[b] > 0.0)) return fail(PNODE_EINVAL, "dt must be positive for active trajectories");
+  }
+  hipLaunchKernelGGL(user_extrapolate_kernel, dim3(unsigned(B)), dim3(64), 0, h->stream, mean_base(h), h->zArgs, h->dK, h->dUserY,
+                     int(B), h->n, int(d), int(k));
+  HIP_TRY(hipGetLastError());
+  std::vector<double> tmp(B * k * d);
+  HIP_TRY(hipMemcpyAsync(tmp.data(), h->dUserY, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  for (size_t b = 0; b < B; ++b)
+    if (active[b]) std::memcpy(y_out + b * k * d, tmp.data() + b * k * d, k * d * sizeof(double));
+  return PNODE_OK;
+}
+
+int pnode_user_set_vf(pnode_batch* h, const double* f, const double* jac) {
+  if (!h || !f) return fail(PNODE_EINVAL, "null argument");
+  if (h->cfg.vf_id != PNODE_VF_USER) return fail(PNODE_ESTATE, "pnode_user_set_vf needs vf_id = PNODE_VF_USER");
+  if (!jac && h->cfg.correction == PNODE_CORR_TS1) return fail(PNODE_EINVAL, "correction_ts1 needs the Jacobian");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  const size_t B = h->cfg.batch, d = h->cfg.d, k = h->cfg.ode_order;
+  HIP_TRY(hipMemcpyAsync(h->dUserF, f, B * d * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (jac) HIP_TRY(hipMemcpyAsync(h->dUserJ, jac, B * d * k * d * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return PNODE_OK;
+}
+
 int pnode_commit(pnode_batch* h, const uint8_t* accept) {
   if (!h || !accept) return fail(PNODE_EINVAL, "null argument");
   if (!h->initialised) return fail(PNODE_ESTATE, "set_initial has not been called");
@@ -487,6 +550,8 @@ int pnode_solve_adaptive_save_at(pnode_batch* h, const double* save_at, int32_t 
   if (!h || !save_at || !dt0 || !ctrl || !num_steps_out || !num_attempts_out || !failed_out)
     return fail(PNODE_EINVAL, "null argument");
   if (!h->initialised) return fail(PNODE_ESTATE, "set_initial has not been called");
+  if (h->cfg.vf_id == PNODE_VF_USER)
+    return fail(PNODE_EINVAL, "host-evaluated vector fields are driven attempt by attempt (pnode_user_extrapolate / pnode_user_set_vf)");
   const size_t B = h->cfg.batch;
   const int K = num_save - 1;
   if (K < 1 || K > h->cfg.num_checkpoints) return fail(PNODE_EINVAL, "num_save - 1 must be in 1..num_checkpoints");
@@ -711,6 +776,7 @@ int pnode_solve_fixed_grid(pnode_batch* h, const double* grid, int32_t G, int32_
   if (!h || !grid || !u_out || G < 1) return fail(PNODE_EINVAL, "bad argument");
   if (!h->initialised) return fail(PNODE_ESTATE, "set_initial has not been called");
   if (h->dense && h->dn.fixedpoint) return fail(PNODE_EINVAL, "solve_fixed_grid: use strategy_filter with the dense model");
+  if (h->cfg.vf_id == PNODE_VF_USER) return fail(PNODE_EINVAL, "solve_fixed_grid replays on the device: it needs a built-in vector field");
   HIP_TRY(hipSetDevice(h->cfg.device));
   const size_t B = h->cfg.batch, n = h->n, d = h->cfg.d;
   std::vector<StepArg> all(size_t(G) * B);

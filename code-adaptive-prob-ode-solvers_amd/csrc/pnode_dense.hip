@@ -101,7 +101,8 @@ __global__ __launch_bounds__(kThreads) void dense_begin_kernel(DenseView v, cons
     }
   }
   __syncthreads();
-  VfCtx ctx{v.vf_id, d, k, v.prm ? v.prm + (v.prm_per_traj ? size_t(b) * v.P : 0) : nullptr};
+  VfCtx ctx{v.vf_id, d, k, v.prm ? v.prm + (v.prm_per_traj ? size_t(b) * v.P : 0) : nullptr,
+            v.user_f ? v.user_f + size_t(b) * d : nullptr, v.user_J ? v.user_J + size_t(b) * d * k * d : nullptr};
   const double tnew = arg.t + arg.dt;
   double* zg = v.z + size_t(b) * d;
   for (int j = threadIdx.x; j < d; j += kThreads) {

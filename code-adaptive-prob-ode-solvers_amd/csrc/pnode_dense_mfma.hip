@@ -540,7 +540,8 @@ __global__ __launch_bounds__(256) void dense_begin_mfma_kernel(DenseView v, cons
     }
   }
   __syncthreads();
-  VfCtx ctx{v.vf_id, d, 1, v.prm ? v.prm + (v.prm_per_traj ? size_t(b) * v.P : 0) : nullptr};
+  VfCtx ctx{v.vf_id, d, 1, v.prm ? v.prm + (v.prm_per_traj ? size_t(b) * v.P : 0) : nullptr,
+            v.user_f ? v.user_f + size_t(b) * d : nullptr, v.user_J ? v.user_J + size_t(b) * d * 1 * d : nullptr};
   const double tnew = arg.t + arg.dt;
   double* zg = v.z + size_t(b) * d;
   for (int j = tid; j < d; j += 256) {

@@ -17,6 +17,8 @@ struct IsoView {
   const double* atol;  // [B]
   const double* rtol;  // [B]
   const double* prm;   // [P] or [B][P]
+  const double* user_f;  // PNODE_VF_USER: [B][d]
+  const double* user_J;  // PNODE_VF_USER: [B][d][k*d]
   double* errnorm;     // [B]
   double* ck_mean;     // [B][K][n][d]
   double* ck_fac;      // [B][K][n][n]
@@ -43,6 +45,8 @@ struct DenseView {
   const double* atol;
   const double* rtol;
   const double* prm;
+  const double* user_f;  // PNODE_VF_USER: [B][d]
+  const double* user_J;  // PNODE_VF_USER: [B][d][k*d]
   double* errnorm;  // [B]
   double* ck_mean;  // [B][K][n][d]
   int64_t* ck_steps;

@@ -263,7 +263,8 @@ __device__ __forceinline__ double iso_attempt(const IsoView& v, const IwpConst& 
   }
 
   // --- pass B: residual z = m^-[k] - f(m^-[<k])  and its norm
-  VfCtx ctx{v.vf_id, d, k, v.prm ? v.prm + (v.prm_per_traj ? size_t(b) * v.P : 0) : nullptr};
+  VfCtx ctx{v.vf_id, d, k, v.prm ? v.prm + (v.prm_per_traj ? size_t(b) * v.P : 0) : nullptr,
+            v.user_f ? v.user_f + size_t(b) * d : nullptr, v.user_J ? v.user_J + size_t(b) * d * k * d : nullptr};
   const double tnew = arg.t + dt;
   double zz = 0.0;
   for (int j = lane; j < d; j += kTeam) {

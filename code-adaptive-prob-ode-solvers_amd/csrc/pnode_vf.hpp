@@ -18,6 +18,8 @@ struct VfCtx {
   int d;
   int k;              // ode order
   const double* prm;  // per-trajectory parameter block (device memory), may be nullptr
+  const double* uf;   // PNODE_VF_USER: host-evaluated f of this trajectory, [d]
+  const double* uj;   // PNODE_VF_USER: host-evaluated Jacobian, [d][k*d]
 };
 
 __device__ __forceinline__ double pleiades_acc(const double* y, int a, bool want_y) {
@@ -97,6 +99,8 @@ __device__ __forceinline__ double vf_f(const VfCtx& c, const double* y, int a, d
       return c.prm[0] * y[a] * (1.0 - c.prm[1] * y[a]);
     case PNODE_VF_LINEAR:
       return c.prm[0] * y[a];
+    case PNODE_VF_USER:
+      return c.uf[a];
     default:
       return 0.0;
   }
@@ -151,6 +155,8 @@ __device__ __forceinline__ double vf_jac(const VfCtx& c, const double* y, int a,
       return a == b ? c.prm[0] * (1.0 - 2.0 * c.prm[1] * y[a]) : 0.0;
     case PNODE_VF_LINEAR:
       return a == b ? c.prm[0] : 0.0;
+    case PNODE_VF_USER:
+      return c.uj[size_t(a) * c.k * c.d + i * c.d + b];
     default:
       return 0.0;
   }

@@ -21,7 +21,7 @@ CALIBRATION = {"none": 0, "dynamic": 1}
 
 SYMBOLS = (
     "pnode_last_error pnode_version pnode_device_count pnode_create pnode_destroy pnode_set_initial "
-    "pnode_set_tolerances pnode_attempt_step pnode_commit pnode_interpolate pnode_checkpoint_at_step "
+    "pnode_set_tolerances pnode_attempt_step pnode_user_extrapolate pnode_user_set_vf pnode_commit pnode_interpolate pnode_checkpoint_at_step "
     "pnode_solve_fixed_grid pnode_solve_adaptive_save_at pnode_solve_adaptive_save_at_device pnode_read_mean pnode_read_time pnode_read_output_scale pnode_read_factor "
     "pnode_read_checkpoint_means pnode_smooth_checkpoint_means pnode_last_step_ms pnode_set_phase_timing "
     "pnode_last_phase_ms pnode_set_generic_path pnode_stream"
@@ -89,6 +89,8 @@ def load_library():
     lib.pnode_set_initial.argtypes = [vp, dp, dp, dp]
     lib.pnode_set_tolerances.argtypes = [vp, dp, dp]
     lib.pnode_attempt_step.argtypes = [vp, dp, u8p, dp]
+    lib.pnode_user_extrapolate.argtypes = [vp, dp, u8p, dp]
+    lib.pnode_user_set_vf.argtypes = [vp, dp, dp]
     lib.pnode_commit.argtypes = [vp, u8p]
     lib.pnode_interpolate.argtypes = [vp, dp, i32p]
     lib.pnode_checkpoint_at_step.argtypes = [vp, i32p]
@@ -199,6 +201,21 @@ class Batch:
         active = np.ascontiguousarray(active, dtype=np.uint8)
         _check(self._lib.pnode_attempt_step(self._h, _dp(dt), active.ctypes.data_as(C.POINTER(C.c_uint8)), _dp(err_out)))
         return err_out
+
+    def user_extrapolate(self, dt, active, ode_order):
+        """PNODE_VF_USER: extrapolated means m^-[:ode_order] (B, k, d) at which the host evaluates the vector field."""
+        y = np.zeros((self.B, ode_order, self.d))
+        active = np.ascontiguousarray(active, dtype=np.uint8)
+        _check(self._lib.pnode_user_extrapolate(self._h, _dp(_f64(dt, (self.B,))), active.ctypes.data_as(C.POINTER(C.c_uint8)), _dp(y)))
+        return y
+
+    def user_set_vf(self, f, jac=None):
+        f = _f64(f, (self.B, self.d))
+        jp = None
+        if jac is not None:
+            jac = _f64(jac)
+            jp = _dp(jac)
+        _check(self._lib.pnode_user_set_vf(self._h, _dp(f), jp))
 
     def commit(self, accept):
         accept = np.ascontiguousarray(accept, dtype=np.uint8)

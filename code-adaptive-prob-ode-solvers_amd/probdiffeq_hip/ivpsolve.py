@@ -20,7 +20,7 @@ import numpy as np
 
 from . import _backend
 from .ivpsolvers import InitialCondition, Solver
-from .vector_fields import VectorField
+from .vector_fields import UserVectorField, VectorField
 
 
 @dataclasses.dataclass(frozen=True)
@@ -86,11 +86,12 @@ class Solution:
     num_attempts: np.ndarray = None
 
 
-def _as_vf(vf) -> VectorField:
-    if not isinstance(vf, VectorField):
+def _as_vf(vf):
+    if not isinstance(vf, (VectorField, UserVectorField)):
         raise TypeError(
-            "vector_field must be a probdiffeq_hip.vector_fields.VectorField (device code + analytic "
-            "Jacobian selected by id); arbitrary Python callables cannot run inside the HIP step kernel."
+            "vector_field must be a probdiffeq_hip.vector_fields.VectorField (device code + analytic Jacobian "
+            "selected by id) or a vector_fields.user(fun, d, ode_order) wrapper (host-evaluated escape hatch); a bare "
+            "Python callable cannot run inside the HIP step kernel."
         )
     return vf
 
@@ -121,9 +122,11 @@ def _make_batch(vf, init: InitialCondition, solver: Solver, num_checkpoints, dev
 class _AdaptiveLoop:
     """Host-sequential controller state for one batch."""
 
-    def __init__(self, batch, asolver: AdaptiveSolver, t0, dt0):
+    def __init__(self, batch, asolver: AdaptiveSolver, t0, dt0, vf=None):
         B = batch.B
         self.batch = batch
+        self.user_vf = vf if isinstance(vf, UserVectorField) else None
+        self.needs_jac = asolver.solver.strategy.correction.kind == "ts1"
         self.ctrl = asolver.control
         self.rate = asolver.solver.error_contraction_rate
         self.nz = asolver.numerical_zero
@@ -145,6 +148,15 @@ class _AdaptiveLoop:
         if self.ctrl.clip and t1 is not None:
             dt = np.where(active, np.minimum(dt, t1 - self.t), dt)
         dt_used = np.where(active, dt, 1.0)
+        if self.user_vf is not None:
+            # host-evaluated vector field: fetch the extrapolated means, evaluate f (and J), hand them to the device
+            k = self.user_vf.ode_order
+            y = self.batch.user_extrapolate(dt_used, active, k)
+            ys = [np.ascontiguousarray(y[:, i]) for i in range(k)]
+            tq = self.t + dt_used
+            f = np.asarray(self.user_vf(*ys, t=tq[:, None]), dtype=np.float64)
+            jac = self.user_vf.jacobian(ys, tq[:, None]) if self.needs_jac else None
+            self.batch.user_set_vf(f, jac)
         err = self.batch.attempt_step(dt_used, active, self._err)
         if self.time_device:
             self.device_ms += self.batch.last_step_ms()
@@ -228,8 +240,8 @@ def solve_adaptive_save_at(vector_field, initial_condition: InitialCondition, sa
     batch = _make_batch(vector_field, init, solver, K, device)
     batch.set_initial(init.tcoeffs, sa_b[:, 0], init.output_scale)
     batch.set_tolerances(adaptive_solver.atol, adaptive_solver.rtol)
-    loop = _AdaptiveLoop(batch, adaptive_solver, sa_b[:, 0], dt0)
-    if python_controller:
+    loop = _AdaptiveLoop(batch, adaptive_solver, sa_b[:, 0], dt0, vf=vector_field)
+    if python_controller or loop.user_vf is not None:
         cursor, num_steps = _python_save_at_loop(batch, loop, sa_b, K, adaptive_solver.numerical_zero)
     else:
         # native driver: same controller arithmetic and call sequence, in C++ inside libpnode_hip.so
@@ -281,7 +293,7 @@ def solve_adaptive_save_every_step(vector_field, initial_condition: InitialCondi
     batch = _make_batch(vector_field, init, solver, 1, device)
     batch.set_initial(init.tcoeffs, t0b, init.output_scale)
     batch.set_tolerances(adaptive_solver.atol, adaptive_solver.rtol)
-    loop = _AdaptiveLoop(batch, adaptive_solver, t0b, dt0)
+    loop = _AdaptiveLoop(batch, adaptive_solver, t0b, dt0, vf=vector_field)
     ts = [[t0b[b]] for b in range(B)]
     ms = [[init.tcoeffs[b]] for b in range(B)]
     while True:

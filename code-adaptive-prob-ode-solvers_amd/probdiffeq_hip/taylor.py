@@ -81,6 +81,17 @@ class Series:
     def map_linear(self, fn):
         return Series([fn(x) for x in self.c])
 
+    def __getitem__(self, idx):
+        """Component selection, applied to every coefficient (so user vector fields can slice their state)."""
+        return Series([x[idx] for x in self.c])
+
+
+def concatenate(parts, axis=-1):
+    """np.concatenate that also accepts truncated series (for vector fields written once for arrays and Series)."""
+    if isinstance(parts[0], Series):
+        return Series([np.concatenate([q.c[k] for q in parts], axis=axis) for k in range(parts[0].order)])
+    return np.concatenate(parts, axis=axis)
+
 
 def _derivatives(vf, u0s, num):
     k = len(u0s)

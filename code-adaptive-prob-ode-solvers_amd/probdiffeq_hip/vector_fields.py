@@ -21,6 +21,7 @@ VF_PLEIADES_ORDER2 = 4
 VF_PLEIADES_ORDER1 = 5
 VF_LOGISTIC = 6
 VF_LINEAR = 7
+VF_USER = 100
 
 
 @dataclasses.dataclass(frozen=True)
@@ -182,3 +183,66 @@ def logistic(a=1.0, b=1.0, d=1):
 
 def linear(lam, d=1):
     return VectorField(VF_LINEAR, d, 1, (float(lam),), "linear")
+
+
+@dataclasses.dataclass(frozen=True)
+class UserVectorField:
+    """Escape hatch for ODEs that are not built into the device code (PNODE_VF_USER).
+
+    `fun(*ys, t)` is an ordinary NumPy function with the reference's calling convention; it must broadcast over a
+    leading batch axis (ys[i] has shape (B, d)) and, for the Taylor initialisation, consist of + - * / ** so that it
+    also runs on `taylor.Series`. The HOST evaluates it for the whole batch before every attempted step (one extra
+    device round trip per attempt), so this path trades speed for generality; `jac(*ys, t) -> (B, d, k*d)` is used
+    with correction_ts1 (default: complex-step differentiation of `fun`, exact to rounding for analytic `fun`).
+    """
+
+    fun: object
+    d: int
+    ode_order: int = 1
+    jac: object = None
+    name: str = "user"
+    vf_id: int = VF_USER
+    params: tuple = ()
+
+    def bind(self, p):
+        if p is None or (hasattr(p, "__len__") and len(p) == 0):
+            return self
+        return dataclasses.replace(self, fun=_Bound(self.fun, p))
+
+    def param_array(self):
+        return np.zeros(0)
+
+    def __call__(self, *ys, t=0.0, p=None):
+        f = self.bind(p).fun if p is not None else self.fun
+        return f(*ys, t=t)
+
+    def series(self, *ys):
+        return self.fun(*ys, t=0.0)
+
+    def jacobian(self, ys, t):
+        """(B, d, k*d) Jacobian at ys = [(B, d)] * k."""
+        if self.jac is not None:
+            return np.asarray(self.jac(*ys, t=t), dtype=np.float64)
+        k, d = self.ode_order, self.d
+        B = ys[0].shape[0]
+        out = np.zeros((B, d, k * d))
+        h = 1e-30
+        for i in range(k):
+            for c in range(d):
+                yc = [np.array(y, dtype=np.complex128) for y in ys]
+                yc[i][:, c] += 1j * h
+                out[:, :, i * d + c] = np.imag(self.fun(*yc, t=t)) / h
+        return out
+
+
+@dataclasses.dataclass(frozen=True)
+class _Bound:
+    fun: object
+    p: object
+
+    def __call__(self, *ys, t=0.0):
+        return self.fun(*ys, t=t, p=self.p)
+
+
+def user(fun, d, ode_order=1, jac=None, name="user"):
+    return UserVectorField(fun, int(d), int(ode_order), jac, name)

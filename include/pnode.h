@@ -56,6 +56,11 @@ extern "C" {
 #define PNODE_VF_LOGISTIC 6      /* ivps.py:8-17 (diffeqzoo logistic); d = 1, order 1; [a, b]         */
 #define PNODE_VF_LINEAR 7        /* test problem u' = lam * u (diagonal); d arbitrary; [lam]          */
 
+/* Escape hatch for vector fields that are not built in: the HOST evaluates f (and, for correction_ts1, the Jacobian)
+ * for the whole batch at the extrapolated means and hands the values over before each attempt
+ * (pnode_user_extrapolate -> user code -> pnode_user_set_vf -> pnode_attempt_step). Any d, order 1 or 2. */
+#define PNODE_VF_USER 100
+
 #define PNODE_MAX_VF_PARAMS 8
 
 typedef struct pnode_config {
@@ -104,6 +109,13 @@ int pnode_set_tolerances(pnode_batch* h, const double* atol, const double* rtol)
  * Replaces the body of the rejection loop inside ivpsolve.solve_adaptive_* (ivpsolvers.py:71-77,
  * run.py:82-90,122-129, vdp.py:77-79) up to — not including — the PI controller. Synchronous. */
 int pnode_attempt_step(pnode_batch* h, const double* dt, const uint8_t* active, double* err_norm_out);
+
+/* PNODE_VF_USER only. Extrapolated means m^-[0..k-1] of the attempt about to be made with these dt:
+ * y_out [B][ode_order][d] (rows of inactive trajectories are left untouched). */
+int pnode_user_extrapolate(pnode_batch* h, const double* dt, const uint8_t* active, double* y_out);
+/* PNODE_VF_USER only. f: [B][d] vector-field values at y_out; jac: [B][d][ode_order*d] with
+ * jac[b][a][i*d + c] = d f_a / d u^(i)_c (may be NULL with correction_ts0). Consumed by the next attempt_step. */
+int pnode_user_set_vf(pnode_batch* h, const double* f, const double* jac);
 
 /* Accept/reject decision taken by the host controller: where accept[b] != 0,
  * INTERP_FROM <- STEP_FROM, STEP_FROM <- PROPOSED (slot rotation, no copies), t += dt, steps += 1. */

@@ -513,3 +513,50 @@ def test_edge_cases_single_checkpoint_ragged_save_at_and_nan_propagation(hip_lib
     assert abs(sol.u[0, -1, 0] - ex(0.1, 2.0)) < 1e-4 and abs(sol.u[2, -1, 0] - ex(0.3, 3.0)) < 1e-4
     # the diverging member (blow-up at t = log(6/5) ~ 0.18) never reaches its later checkpoints
     assert not np.all(np.isfinite(sol.u[1])) or sol.num_steps[1, -1] == 0 or np.max(np.abs(sol.u[1])) > 1e3
+
+
+def test_user_vector_field_escape_hatch(hip_lib):
+    """A vector field that is NOT built into the device code (host-evaluated, PNODE_VF_USER): Lotka-Volterra, isotropic
+    EKF0 and dense EKF1, against the oracle driven by the same NumPy function and against scipy."""
+    from scipy.integrate import solve_ivp
+
+    def lotka(y, *, t, p=(1.5, 1.0, 3.0, 1.0)):
+        a, bb, c, dd = p
+        u, v = y[..., 0:1], y[..., 1:2]
+        from probdiffeq_hip import taylor
+
+        return taylor.concatenate([a * u - bb * u * v, dd * u * v - c * v])
+
+    vf = V.user(lotka, d=2, ode_order=1, name="lotka_volterra")
+    u0 = np.array([[1.0, 1.0], [1.5, 0.7]])
+    save_at = np.linspace(0.0, 2.0, 5)
+    truth = np.stack([solve_ivp(lambda t, y: lotka(y, t=t), (0, 2.0), u, rtol=1e-12, atol=1e-12, t_eval=save_at).y.T for u in u0])
+    for model, corr, tol in (("isotropic", "ts0", 1e-6), ("dense", "ts1", 1e-6)):
+        impl.select(model, ode_shape=(2,))
+        correction = ivpsolvers.correction_ts0() if corr == "ts0" else ivpsolvers.correction_ts1()
+        solver = ivpsolvers.solver_dynamic(ivpsolvers.strategy_filter(ivpsolvers.prior_ibm(3), correction))
+        tcs = tcoeffs(vf, [u0], 3)
+        init = solver.initial_condition(tcs, 1.0)
+        sol = ivpsolve.solve_adaptive_save_at(vf, init, save_at=save_at, dt0=0.05, adaptive_solver=ivpsolve.adaptive(solver, atol=tol, rtol=tol))
+        assert np.max(np.abs(sol.u - truth)) < 1e-4
+        cfg = po.SolverConfig(nu=3, model=model, correction=corr, strategy="filter", calibration="dynamic")
+
+        def f1(y, t):
+            return lotka(y[0], t=t)
+
+        def j1(y, t):
+            J = np.zeros((2, 1, 2))
+            h = 1e-30
+            for c in range(2):
+                yc = np.array(y[0], dtype=np.complex128)
+                yc[c] += 1j * h
+                J[:, 0, c] = np.imag(lotka(yc, t=t)) / h
+            return J
+
+        prob = po.Problem(f1, j1, 1, 2)
+        for b in range(2):
+            osol = po.solve_adaptive_save_at(cfg, po.AdaptiveConfig(tol, tol), prob, po.initial_state(cfg, [c[b] for c in tcs], 0.0), save_at, 0.05)
+            # f is evaluated at the host's copy of the extrapolated mean (1 ulp away from the kernel's): allow a
+            # single accept/reject decision to differ
+            assert np.max(np.abs(sol.num_steps[b] - osol.num_steps)) <= 2
+            assert relmax(sol.u[b], osol.u) < 1e-6
