@@ -662,7 +662,9 @@ int pnode_solve_adaptive_save_at_device(pnode_batch* h, const double* save_at, i
   if (!h || !save_at || !dt0 || !ctrl || !num_steps_out || !num_attempts_out || !failed_out)
     return fail(PNODE_EINVAL, "null argument");
   if (!h->initialised) return fail(PNODE_ESTATE, "set_initial has not been called");
-  if (h->dense) return fail(PNODE_EINVAL, "the device-resident controller is implemented for the isotropic model");
+  if (h->dense && !(dense_small_supported(h->dn) && !h->dn.force_generic))
+    return fail(PNODE_EINVAL, "the device-resident controller needs the isotropic model or a dense model with (nu+1)*d <= 32");
+  if (h->cfg.vf_id == PNODE_VF_USER) return fail(PNODE_EINVAL, "the device-resident controller needs a built-in vector field");
   HIP_TRY(hipSetDevice(h->cfg.device));
   const size_t B = h->cfg.batch;
   const int K = num_save - 1;
@@ -749,7 +751,10 @@ int pnode_solve_adaptive_save_at_device(pnode_batch* h, const double* save_at, i
       c.s_sf = h->s_sf[b]; c.s_if = h->s_if[b]; c.s_pr = h->s_pr[b];
     }
     if (!any) break;
-    iso_launch_advance(h->iso, zCtl, h->dK, cp, h->stream);
+    if (h->dense)
+      dense_small_launch_advance(h->dn, zCtl, h->dK, cp, h->stream);
+    else
+      iso_launch_advance(h->iso, zCtl, h->dK, cp, h->stream);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) {

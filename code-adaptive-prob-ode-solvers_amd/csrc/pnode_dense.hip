@@ -372,6 +372,11 @@ void dense_launch_step(const DenseView& v, const StepArg* args, const IwpConst* 
     if (ev) (void)hipEventRecord(ev->ev[i], s);
   };
   mark(0);
+  if (dense_small_supported(v) && !v.force_generic) {
+    dense_small_launch_step(v, args, K, s);
+    mark(1); mark(2); mark(3); mark(4);
+    return;
+  }
   const bool fast = dense_mfma_supported(v) && !v.force_generic;
   const size_t shm_begin = (size_t(v.k) * v.d + v.d + 4 + size_t(v.n) * v.n) * sizeof(double);
   if (fast && v.ts1 && !(v.ablate & 32))

@@ -1,0 +1,322 @@
+// Dense EKF1/EKF0 for SMALL state dimensions (D = n*d <= 32): one wavefront per trajectory, the whole attempted
+// step fused in ONE kernel with every matrix in LDS (the north star's "stage the (nu+1)d x (nu+1)d blocks in LDS").
+// This is the shape of the reference's own dense run — stiff Van der Pol, d = 1, nu = 4, D = 5
+// (/root/reference/experiments/1_van_der_pol/vdp.py:61-66) — and of BASELINE config 2 (tolerance sweep, B = 256).
+// Same algorithm as pnode_dense.hip (generic path): row-Householder LQ time update, Gram-of-factor innovation,
+// projector-form measurement update. Lane j owns row j in the O(D^3) loops, so there are no cross-lane reductions
+// except the pivot-row norm. Also provides the device-resident controller loop (dense_small_advance_kernel).
+#include "pnode_device.hpp"
+
+namespace pnode {
+
+struct SmallLds {
+  double *L, *Mt, *T, *F, *J, *S, *mext, *z, *wz, *errv, *y, *lq, *p, *pinv, *tmp;
+};
+
+__host__ __device__ inline size_t small_lds_doubles(int D, int d, int k, int n) {
+  const int LD = D + 1;
+  return size_t(3) * D * LD + size_t(d) * LD + size_t(d) * k * d + size_t(d) * (d + 1) + D + 4 * size_t(d) + size_t(k) * d +
+         size_t(n) * n + 2 * size_t(n) + 8;
+}
+
+__device__ __forceinline__ SmallLds small_carve(double* base, int D, int d, int k, int n) {
+  const int LD = D + 1;
+  SmallLds s;
+  s.L = base;
+  s.Mt = s.L + D * LD;
+  s.T = s.Mt + D * LD;
+  s.F = s.T + D * LD;
+  s.J = s.F + d * LD;
+  s.S = s.J + d * k * d;
+  s.mext = s.S + d * (d + 1);
+  s.z = s.mext + D;
+  s.wz = s.z + d;
+  s.errv = s.wz + d;
+  s.tmp = s.errv + d;
+  s.y = s.tmp + d;
+  s.lq = s.y + k * d;
+  s.p = s.lq + n * n;
+  s.pinv = s.p + n;
+  return s;
+}
+
+__device__ __forceinline__ void wsync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+}
+
+// One attempted step by one wavefront; returns the normalised error norm (wave-uniform).
+__device__ double dense_small_attempt(const DenseView& v, const IwpConst& K, int b, int lane, const StepArg& arg, double* lds) {
+  const int d = v.d, k = v.k, n = v.n, D = v.D, kd = k * d, LD = D + 1, LS = d + 1;
+  SmallLds s = small_carve(lds, D, d, k, n);
+  const size_t sB = size_t(v.B);
+  // preconditioner + P chol(Qbar)
+  if (lane == 0) {
+    const double adt = fabs(arg.dt);
+    double pw = sqrt(adt);
+    for (int i = n - 1; i >= 0; --i) {
+      s.p[i] = pw / K.fact[i];
+      s.pinv[i] = K.fact[i] / pw;
+      pw *= adt;
+    }
+  }
+  wsync();
+  for (int idx = lane; idx < n * n; idx += kWave) {
+    const int i = idx / n, j = idx % n;
+    s.lq[idx] = (j <= i) ? s.p[i] * K.qsT[j][i] : 0.0;
+  }
+  const double* msrc = v.mean + (size_t(arg.src) * sB + b) * D;
+  double* mdst = v.mean + (size_t(arg.dst) * sB + b) * D;
+  const double* Lsrc = v.U + (size_t(arg.src) * sB + b) * D * D;
+  for (int idx = lane; idx < D * D; idx += kWave) s.L[(idx / D) * LD + idx % D] = Lsrc[idx];
+  for (int r = lane; r < D; r += kWave) {
+    const int i = r / d, j = r % d;
+    double acc = 0.0;
+    for (int kk = i; kk < n; ++kk) acc += K.a[i][kk] * s.pinv[kk] * msrc[kk * d + j];
+    const double e = s.p[i] * acc;
+    s.mext[r] = e;
+    if (i < k) s.y[r] = e;
+  }
+  wsync();
+  VfCtx ctx{v.vf_id, d, k, v.prm ? v.prm + (v.prm_per_traj ? size_t(b) * v.P : 0) : nullptr,
+            v.user_f ? v.user_f + size_t(b) * d : nullptr, v.user_J ? v.user_J + size_t(b) * d * k * d : nullptr};
+  const double tnew = arg.t + arg.dt;
+  for (int j = lane; j < d; j += kWave) {
+    const double z = s.mext[k * d + j] - vf_f(ctx, s.y, j, tnew);
+    s.z[j] = z;
+    s.tmp[j] = z;
+  }
+  if (v.ts1)
+    for (int idx = lane; idx < d * kd; idx += kWave) s.J[idx] = vf_jac(ctx, s.y, idx / kd, (idx % kd) / d, idx % d, tnew);
+  wsync();
+  // S1 = sum_{j <= k} B_j B_j^T,  B_j = lq[k][j] I - sum_{i<k} lq[i][j] J_i
+  for (int idx = lane; idx < d * d; idx += kWave) {
+    const int a = idx / d, a2 = idx % d;
+    if (a2 > a) continue;
+    double acc = 0.0;
+    for (int j = 0; j <= k; ++j) {
+      const double lk = s.lq[k * n + j];
+      if (!v.ts1) {
+        if (a == a2) acc += lk * lk;
+        continue;
+      }
+      for (int c = 0; c < d; ++c) {
+        double ba = (a == c) ? lk : 0.0, ba2 = (a2 == c) ? lk : 0.0;
+        for (int i = 0; i < k; ++i) {
+          const double l = s.lq[i * n + j];
+          ba -= l * s.J[a * kd + i * d + c];
+          ba2 -= l * s.J[a2 * kd + i * d + c];
+        }
+        acc += ba * ba2;
+      }
+    }
+    s.S[a * LS + a2] = acc;
+    if (a == a2) s.errv[a] = acc;
+  }
+  wsync();
+  // Cholesky of S1 (lower, in place) + forward solve of z; lane r owns row r
+  for (int c = 0; c < d; ++c) {
+    const double piv = sqrt(s.S[c * LS + c]);
+    wsync();
+    for (int r = c + lane; r < d; r += kWave) s.S[r * LS + c] = (r == c) ? piv : s.S[r * LS + c] / piv;
+    wsync();
+    for (int r = c + 1 + lane; r < d; r += kWave)
+      for (int q = c + 1; q <= r; ++q) s.S[r * LS + q] -= s.S[r * LS + c] * s.S[q * LS + c];
+    wsync();
+  }
+  for (int a = 0; a < d; ++a) {
+    const double xa = s.tmp[a] / s.S[a * LS + a];
+    wsync();
+    if (lane == 0) s.tmp[a] = xa;
+    for (int r = a + 1 + lane; r < d; r += kWave) s.tmp[r] -= s.S[r * LS + a] * xa;
+    wsync();
+  }
+  double ww = 0.0;
+  for (int j = lane; j < d; j += kWave) ww += s.tmp[j] * s.tmp[j];
+  ww = wave_sum(ww);
+  const double sigma_hat = sqrt(ww / double(d));
+  const double sigma = v.dynamic ? sigma_hat : v.sigma[size_t(arg.src) * sB + b];
+  for (int j = lane; j < d; j += kWave) s.errv[j] = arg.dt * sigma_hat * sqrt(s.errv[j]);
+  // LQ input: Mt = (Abar P^-1 (x) I) L ,  T = sigma chol(Qbar) (x) I
+  for (int idx = lane; idx < D * D; idx += kWave) {
+    const int r = idx / D, c = idx % D;
+    const int i = r / d, q = r % d;
+    double acc = 0.0;
+    for (int kk = i; kk < n; ++kk) acc += K.a[i][kk] * s.pinv[kk] * s.L[(kk * d + q) * LD + c];
+    s.Mt[r * LD + c] = acc;
+    const int j = c / d, q2 = c % d;
+    s.T[r * LD + c] = (q2 == q && j <= i) ? sigma * K.qsT[j][i] : 0.0;
+  }
+  wsync();
+  // row-Householder LQ of [T | Mt]; lane j owns row j in the update
+  for (int c = 0; c < D; ++c) {
+    double part = 0.0;
+    for (int q = lane; q < D; q += kWave) part += s.Mt[c * LD + q] * s.Mt[c * LD + q];
+    const double xx = wave_sum(part);
+    if (xx != 0.0) {
+      const double alpha = s.T[c * LD + c];
+      const double beta = -copysign(sqrt(alpha * alpha + xx), alpha);
+      const double tau = (beta - alpha) / beta, scale = 1.0 / (alpha - beta);
+      for (int j = c + 1 + lane; j < D; j += kWave) {
+        double dot = 0.0;
+        for (int q = 0; q < D; ++q) dot += s.Mt[j * LD + q] * s.Mt[c * LD + q];
+        const double tjc = s.T[j * LD + c];
+        const double w = tau * (tjc + scale * dot);
+        const double ws = w * scale;
+        for (int q = 0; q < D; ++q) s.Mt[j * LD + q] -= ws * s.Mt[c * LD + q];
+        s.T[j * LD + c] = tjc - w;
+      }
+      if (lane == 0) s.T[c * LD + c] = beta;
+    }
+    wsync();
+  }
+  // L^- = diag(p) T  (into s.L), F = H L^-
+  for (int idx = lane; idx < D * D; idx += kWave) {
+    const int r = idx / D, c = idx % D;
+    s.L[r * LD + c] = (c <= r) ? s.p[r / d] * s.T[r * LD + c] : 0.0;
+  }
+  wsync();
+  for (int idx = lane; idx < d * D; idx += kWave) {
+    const int a = idx / D, c = idx % D;
+    double acc = s.L[(k * d + a) * LD + c];
+    if (v.ts1)
+      for (int i = 0; i < k; ++i)
+        for (int q = 0; q < d; ++q) acc -= s.J[a * kd + i * d + q] * s.L[(i * d + q) * LD + c];
+    s.F[a * LD + c] = acc;
+  }
+  wsync();
+  for (int idx = lane; idx < d * d; idx += kWave) {
+    const int a = idx / d, a2 = idx % d;
+    if (a2 > a) continue;
+    double acc = 0.0;
+    for (int c = 0; c < D; ++c) acc += s.F[a * LD + c] * s.F[a2 * LD + c];
+    s.S[a * LS + a2] = acc;
+  }
+  for (int j = lane; j < d; j += kWave) s.wz[j] = s.z[j];
+  wsync();
+  for (int c = 0; c < d; ++c) {
+    const double piv = sqrt(s.S[c * LS + c]);
+    wsync();
+    for (int r = c + lane; r < d; r += kWave) s.S[r * LS + c] = (r == c) ? piv : s.S[r * LS + c] / piv;
+    wsync();
+    for (int r = c + 1 + lane; r < d; r += kWave)
+      for (int q = c + 1; q <= r; ++q) s.S[r * LS + q] -= s.S[r * LS + c] * s.S[q * LS + c];
+    wsync();
+  }
+  // W = C^-1 F (lane = column), wz = C^-1 z (lane D)
+  for (int c = lane; c < D + 1; c += kWave) {
+    double* col = (c < D) ? (s.F + c) : s.wz;
+    const int ld = (c < D) ? LD : 1;
+    for (int a = 0; a < d; ++a) {
+      const double w = col[a * ld] / s.S[a * LS + a];
+      col[a * ld] = w;
+      for (int a2 = a + 1; a2 < d; ++a2) col[a2 * ld] -= s.S[a2 * LS + a] * w;
+    }
+  }
+  wsync();
+  // Y = L^- W^T (row per lane, kept in Mt[:, 0:d]); mean; L_new
+  for (int r = lane; r < D; r += kWave) {
+    double mnew = s.mext[r];
+    for (int a = 0; a < d; ++a) {
+      double acc = 0.0;
+      for (int c = 0; c <= r; ++c) acc += s.L[r * LD + c] * s.F[a * LD + c];
+      s.Mt[r * LD + a] = acc;
+      mnew -= acc * s.wz[a];
+    }
+    mdst[r] = mnew;
+    s.mext[r] = mnew;
+  }
+  wsync();
+  double* Ln = v.U + (size_t(arg.dst) * sB + b) * D * D;
+  for (int idx = lane; idx < D * D; idx += kWave) {
+    const int r = idx / D, c = idx % D;
+    double acc = s.L[r * LD + c];
+    for (int a = 0; a < d; ++a) acc -= s.Mt[r * LD + a] * s.F[a * LD + c];
+    Ln[idx] = acc;
+  }
+  const double atol = v.atol[b], rtol = v.rtol[b];
+  double part = 0.0;
+  for (int j = lane; j < d; j += kWave) {
+    const double rel = s.errv[j] / (atol + rtol * fabs(s.mext[j]));
+    part += rel * rel;
+  }
+  part = wave_sum(part);
+  if (lane == 0) v.sigma[size_t(arg.dst) * sB + b] = sigma;
+  return sqrt(part / double(d));
+}
+
+__global__ __launch_bounds__(64) void dense_small_step_kernel(DenseView v, const StepArg* __restrict__ args,
+                                                              const IwpConst* __restrict__ Kc) {
+  extern __shared__ double smem[];
+  const int b = blockIdx.x;
+  const StepArg arg = args[b];
+  if (!arg.active) return;
+  const double e = dense_small_attempt(v, *Kc, b, threadIdx.x, arg, smem);
+  if (threadIdx.x == 0) v.errnorm[b] = e;
+}
+
+// Device-resident controller (opt-in; same contract as iso_advance_kernel).
+__global__ __launch_bounds__(64) void dense_small_advance_kernel(DenseView v, TrajCtl* __restrict__ ctl,
+                                                                 const IwpConst* __restrict__ Kc, ControlParams cp) {
+  extern __shared__ double smem[];
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x;
+  TrajCtl c = ctl[b];
+  if (c.status < 0) return;
+  int iters = 0;
+  c.status = 0;
+  while (c.t_sf + cp.numerical_zero < c.t_stop && iters < cp.max_iters) {
+    double dt = c.dt;
+    if (cp.clip) dt = fmin(dt, c.t_stop - c.t_sf);
+    StepArg arg;
+    arg.dt = dt; arg.t = c.t_sf; arg.src = c.s_sf; arg.dst = c.s_pr; arg.active = 1; arg.pad = 0;
+    const double e = dense_small_attempt(v, *Kc, b, lane, arg, smem);
+    __threadfence_block();
+    ++iters;
+    c.attempts += 1;
+    bool accept;
+    if (e != e) {
+      c.status = 2;
+      accept = true;
+    } else {
+      const double le = log(e);
+      const double raw = cp.safety * exp(cp.n2 * c.log_prev - (cp.n1 + cp.n2) * le);
+      const double factor = fmax(cp.factor_min, fmin(raw, cp.factor_max));
+      if (e <= 1.0) c.log_prev = le;
+      c.dt = factor * dt;
+      accept = !(e > 1.0);
+    }
+    if (accept) {
+      c.s_if = c.s_sf;
+      c.t_if = c.t_sf;
+      c.s_sf = c.s_pr;
+      c.t_sf += dt;
+      c.steps += 1;
+      int fr = 0;
+      while (fr == c.s_if || fr == c.s_sf) ++fr;
+      c.s_pr = fr;
+    }
+    if (c.status == 2) break;
+    if (!(isfinite(c.dt) && isfinite(c.t_sf) && c.dt > 0.0)) {
+      c.status = 2;
+      break;
+    }
+  }
+  if (c.status == 0) c.status = (c.t_sf + cp.numerical_zero >= c.t_stop) ? 1 : 3;
+  if (lane == 0) ctl[b] = c;
+}
+
+static size_t small_shm_bytes(const DenseView& v) { return small_lds_doubles(v.D, v.d, v.k, v.n) * sizeof(double); }
+
+bool dense_small_supported(const DenseView& v) { return v.D <= 32 && !v.fixedpoint; }
+
+void dense_small_launch_step(const DenseView& v, const StepArg* args, const IwpConst* K, hipStream_t s) {
+  hipLaunchKernelGGL(dense_small_step_kernel, dim3(v.B), dim3(64), small_shm_bytes(v), s, v, args, K);
+}
+
+void dense_small_launch_advance(const DenseView& v, TrajCtl* ctl, const IwpConst* K, const ControlParams& cp, hipStream_t s) {
+  hipLaunchKernelGGL(dense_small_advance_kernel, dim3(v.B), dim3(64), small_shm_bytes(v), s, v, ctl, K, cp);
+}
+
+}  // namespace pnode

@@ -89,5 +89,9 @@ void dense_fp_launch_interp(const DenseView& v, const InterpArg* iargs, const Fp
                             hipStream_t s);
 void dense_fp_launch_smooth(const DenseView& v, const int32_t* num_filled, double* out, hipStream_t s);
 void dense_launch_lq_generic(const DenseView& v, int rows_total, hipStream_t s);
+// small-D fused path (pnode_dense_small.hip): one wavefront per trajectory, one kernel per attempt
+bool dense_small_supported(const DenseView& v);
+void dense_small_launch_step(const DenseView& v, const StepArg* args, const IwpConst* K, hipStream_t s);
+void dense_small_launch_advance(const DenseView& v, TrajCtl* ctl, const IwpConst* K, const ControlParams& cp, hipStream_t s);
 
 }  // namespace pnode

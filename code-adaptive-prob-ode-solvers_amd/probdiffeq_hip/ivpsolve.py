@@ -225,7 +225,7 @@ def solve_adaptive_save_at(vector_field, initial_condition: InitialCondition, sa
 
     Controller placement: by default the PI controller and the accept/reject decisions run on the host (native
     loop inside the C-ABI; `python_controller=True` runs the same loop in NumPy). `device_controller=True`
-    (isotropic model) moves them into the step kernel: one host synchronisation per checkpoint interval.
+    (isotropic model, or dense model with (nu+1) d <= 32) moves them into the step kernel: one host synchronisation per checkpoint interval.
     """
     solver = adaptive_solver.solver
     if not solver.strategy.is_suitable_for_save_at:

@@ -152,9 +152,10 @@ int pnode_solve_adaptive_save_at(pnode_batch* h, const double* save_at, int32_t 
                                  uint8_t* failed_out);
 
 /* Same contract as pnode_solve_adaptive_save_at, with the accept/reject loop and the PI law running ON THE
- * DEVICE (one wavefront per trajectory loops until its next save_at point; SURVEY.md 8(f)-1, opt-in, isotropic
- * model). The host synchronises once per checkpoint interval (or every `iters_per_launch` attempts, <= 0: 4096)
- * and still performs the checkpoint interpolation calls. */
+ * DEVICE (one wavefront per trajectory loops until its next save_at point; SURVEY.md 8(f)-1, opt-in; isotropic
+ * model, or dense model with (nu+1)*d <= 32; built-in vector fields only). The host synchronises once per
+ * checkpoint interval (or every `iters_per_launch` attempts, <= 0: 4096) and still performs the checkpoint
+ * interpolation calls. */
 int pnode_solve_adaptive_save_at_device(pnode_batch* h, const double* save_at, int32_t num_save, int32_t per_trajectory,
                                         const double* dt0, const pnode_control* control, double numerical_zero,
                                         int32_t iters_per_launch, int64_t* num_steps_out, int64_t* num_attempts_out,

@@ -102,6 +102,9 @@ def main():
     vf, u0, (t0, t1), _ = ivps.van_der_pol_first_order(1.0)
     run("C1 vdp mu=1 (single)", vf, [u0[0]], t0, t1, model="isotropic", corr="ts0", strategy="filter", nu=3,
         atol=1e-6, rtol=1e-6, dt0=0.1, device_controller=True)
+    vf, u0, (t0, t1) = ivps.van_der_pol(1e3)
+    run("C2 vdp mu=1e3 EKF1 sweep", vf, [np.tile(u0[0], (256, 1)), np.tile(u0[1], (256, 1))], t0, t1, model="dense", corr="ts1",
+        strategy="filter", nu=4, atol=tols, rtol=tols, dt0=0.01, device_controller=True)
 
 
 if __name__ == "__main__":

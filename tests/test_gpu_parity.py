@@ -169,8 +169,11 @@ def _dense_batch(vf, nu, correction, B, K=2, calibration="dynamic"):
                           num_checkpoints=K)
 
 
+@pytest.mark.parametrize("path", ["default", "generic"])
 @pytest.mark.parametrize("case", ["vdp2", "brusselator8", "rigid", "vdp1_ts0"])
-def test_dense_steps_match_oracle(hip_lib, case):
+def test_dense_steps_match_oracle(hip_lib, case, path):
+    """Single attempted steps of the dense model against the oracle. "default" takes the fused one-wavefront kernel
+    for D <= 32 (vdp2, rigid, vdp1_ts0) and the MFMA kernels for brusselator8; "generic" forces the generic kernels."""
     if case == "vdp2":
         vf, nu, corr, u0s = V.van_der_pol_order2(1e3), 4, "ts1", [np.array([[2.0]]), np.array([[0.0]])]
         dts = [1e-4, 1e-4, 2e-4]
@@ -186,6 +189,8 @@ def test_dense_steps_match_oracle(hip_lib, case):
     tc = tcoeffs(vf, u0s, nu)
     B = 1
     batch = _dense_batch(vf, nu, corr, B)
+    if path == "generic":
+        batch.set_generic_path(True)
     batch.set_initial(np.stack(tc, axis=1), np.zeros(B), np.ones(B))
     batch.set_tolerances(1e-4, 1e-4)
     cfg = po.SolverConfig(nu=nu, model="dense", correction=corr, strategy="filter", calibration="dynamic")
@@ -429,6 +434,52 @@ def test_device_resident_controller_matches_host_controller(hip_lib, golden):
     py = ivpsolve.solve_adaptive_save_at(vf, init, save_at=save_at, dt0=0.1, adaptive_solver=asolver, python_controller=True)
     assert np.array_equal(py.num_steps, host.num_steps)
     assert np.max(np.abs(py.u - host.u)) < 1e-10
+
+
+def test_small_dense_fused_kernel_and_device_controller(hip_lib):
+    """Dense EKF1 with (nu+1) d <= 32 (BASELINE config 2's shape: stiff Van der Pol, d=1, nu=4, tolerance sweep) runs as
+    one fused one-wavefront kernel per attempt. Whole adaptive solves: against the oracle, against the generic kernels,
+    and with the controller resident on the device."""
+    vf = V.van_der_pol_order2(1e3)
+    tols = 10.0 ** np.array([-2.0, -3.0, -4.0, -5.0])
+    B = len(tols)
+    impl.select("dense", ode_shape=(1,))
+    solver = ivpsolvers.solver_dynamic(ivpsolvers.strategy_filter(ivpsolvers.prior_ibm(4), ivpsolvers.correction_ts1(ode_order=2)))
+    u0s = [np.full((B, 1), 2.0), np.zeros((B, 1))]
+    tcs = tcoeffs(vf, u0s, 4)
+    init = solver.initial_condition(tcs, 1.0)
+    save_at = np.linspace(0.0, 1.0, 5)
+    asolver = ivpsolve.adaptive(solver, atol=tols, rtol=tols)
+    host = ivpsolve.solve_adaptive_save_at(vf, init, save_at=save_at, dt0=0.01, adaptive_solver=asolver)
+    dev = ivpsolve.solve_adaptive_save_at(vf, init, save_at=save_at, dt0=0.01, adaptive_solver=asolver, device_controller=True)
+    # identical decisions until the stiff transition near t = 0.8; inside it the accept/reject sequence is chaotic in the
+    # last bits (device vs host libm log/exp in the controller), as between the oracle and the committed JAX grid
+    assert np.array_equal(dev.num_steps[:, :4], host.num_steps[:, :4])
+    assert np.all(np.abs(dev.num_steps[:, -1] - host.num_steps[:, -1]) <= 0.05 * host.num_steps[:, -1])
+    assert np.max(np.abs(dev.u[:, :4] - host.u[:, :4])) < 1e-10
+    assert np.all(np.abs(dev.u[:, -1, 0] - host.u[:, -1, 0]) < 20 * tols)
+    cfg = po.SolverConfig(nu=4, model="dense", correction="ts1", strategy="filter", calibration="dynamic")
+    for b in range(B):
+        osol = po.solve_adaptive_save_at(cfg, po.AdaptiveConfig(tols[b], tols[b]), oracle_problem(vf),
+                                         po.initial_state(cfg, [c[b] for c in tcs], 0.0), save_at, 0.01)
+        assert abs(int(host.num_steps[b, -1]) - int(osol.num_steps[-1])) <= max(2, 0.02 * osol.num_steps[-1]), b
+        assert relmax(host.u[b], osol.u) < 1e-5 * max(1.0, tols[b] / 1e-5), b
+    # non-stiff, d = 3, nu = 2 (D = 9) and d = 8, nu = 3 (D = 32, the largest fused size): identical decisions
+    for vf2, nu, u0 in ((V.rigid_body(), 2, np.array([[1.0, 0.0, 0.9]])), (V.brusselator(4), 3, brusselator_y0(4)[None])):
+        impl.select("dense", ode_shape=(vf2.d,))
+        solver = ivpsolvers.solver_dynamic(ivpsolvers.strategy_filter(ivpsolvers.prior_ibm(nu), ivpsolvers.correction_ts1()))
+        tcs = tcoeffs(vf2, [u0], nu)
+        init = solver.initial_condition(tcs, 1.0)
+        sa = np.linspace(0.0, 2.0, 4)
+        asolver = ivpsolve.adaptive(solver, atol=1e-5, rtol=1e-5)
+        host = ivpsolve.solve_adaptive_save_at(vf2, init, save_at=sa, dt0=0.01, adaptive_solver=asolver)
+        dev = ivpsolve.solve_adaptive_save_at(vf2, init, save_at=sa, dt0=0.01, adaptive_solver=asolver, device_controller=True)
+        cfg = po.SolverConfig(nu=nu, model="dense", correction="ts1", strategy="filter", calibration="dynamic")
+        osol = po.solve_adaptive_save_at(cfg, po.AdaptiveConfig(1e-5, 1e-5), oracle_problem(vf2),
+                                         po.initial_state(cfg, [c[0] for c in tcs], 0.0), sa, 0.01)
+        assert np.array_equal(host.num_steps[0], osol.num_steps), vf2.d
+        assert np.array_equal(dev.num_steps, host.num_steps), vf2.d
+        assert relmax(host.u[0], osol.u) < 1e-8 and np.max(np.abs(dev.u - host.u)) < 1e-11, vf2.d
 
 
 @pytest.mark.parametrize("case", ["brusselator4", "rigid", "vdp2"])
