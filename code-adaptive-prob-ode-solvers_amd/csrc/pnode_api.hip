@@ -315,6 +315,15 @@ int pnode_create(const pnode_config* cfg, pnode_batch** out) {
     ALLOC(v.X, B * D * d);
     ALLOC(v.S, B * d * d);
     ALLOC(v.sig_new, B);
+    {
+      const int DT = int(D) / 16;
+      if (v.ts1 && !v.fixedpoint && d % 32 == 0 && (DT == 8 || DT == 16 || DT == 32 || DT == 48 || DT == 64)) {
+        ALLOC(v.lgG, B * v.mr_rows * D * 32);
+        ALLOC(v.lgW, B * v.mr_rows * D * 32);
+        ALLOC(v.lgTf, B * 32 * 32);
+        ALLOC(v.lgOff, B);
+      }
+    }
     v.atol = h->dAtol; v.rtol = h->dRtol; v.prm = nprm ? h->dPrm : nullptr; v.errnorm = h->zErr;
     v.user_f = h->dUserF; v.user_J = h->dUserJ;
   }
@@ -947,7 +956,9 @@ int pnode_last_step_ms(pnode_batch* h, float* ms_out) {
 
 int pnode_set_generic_path(pnode_batch* h, int32_t enabled) {
   if (!h) return fail(PNODE_EINVAL, "null handle");
-  h->dn.force_generic = enabled != 0;
+  if (enabled == 2 && !dense_large_supported(h->dn)) return fail(PNODE_EINVAL, "the large-D path does not support this shape");
+  h->dn.force_generic = enabled == 1;
+  h->dn.force_large = enabled == 2;
   return PNODE_OK;
 }
 

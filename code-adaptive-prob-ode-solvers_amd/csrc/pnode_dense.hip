@@ -378,6 +378,10 @@ void dense_launch_step(const DenseView& v, const StepArg* args, const IwpConst* 
     return;
   }
   const bool fast = dense_mfma_supported(v) && !v.force_generic;
+  if (dense_large_supported(v) && !v.force_generic && (v.force_large || !fast)) {
+    dense_large_launch_step(v, args, K, s, ev);
+    return;
+  }
   const size_t shm_begin = (size_t(v.k) * v.d + v.d + 4 + size_t(v.n) * v.n) * sizeof(double);
   if (fast && v.ts1 && !(v.ablate & 32))
     dense_launch_mfma_begin(v, args, K, s);
@@ -396,6 +400,11 @@ void dense_launch_step(const DenseView& v, const StepArg* args, const IwpConst* 
   const size_t shm_corr = (size_t(v.d) + 4) * sizeof(double);
   hipLaunchKernelGGL(dense_correct_kernel, dim3(v.B), dim3(kThreads), shm_corr, s, v, args, K);
   mark(4);
+}
+
+void dense_launch_lq_input(const DenseView& v, const StepArg* args, const IwpConst* K, hipStream_t s) {
+  const int rows_per = v.D < 64 ? v.D : 64;
+  hipLaunchKernelGGL(dense_lq_input_kernel, dim3(rows_per, v.B), dim3(kThreads), 0, s, v, args, K);
 }
 
 void dense_launch_lq_generic(const DenseView& v, int rows_total, hipStream_t s) {

@@ -1,0 +1,628 @@
+// Dense EKF1 for LARGE state dimensions (D = (nu+1) d in {128, 256, 512, 768, 1024}, d % 32 == 0): BASELINE config 5
+// (Brusselator N = 128, d = 256, nu = 3, D = 1024 — "MFMA Jacobian x cov path"). One trajectory's factor (8 MB at
+// D = 1024) fits neither registers nor LDS, so the step is a sequence of batched, HBM/L2-tiled kernels:
+//   * gemm_kernel        : C = beta C0 + alpha A op(B), fp64 MFMA 16x16x4, 64x64 or 128x32 tiles staged through LDS,
+//                          register prefetch of the next k-tile; one launch covers all trajectories (blockIdx.z)
+//   * lq_panel_kernel    : row-Householder factorisation of a 32-row panel of [T | Mt] (rows in registers, pivot row
+//                          broadcast through LDS, DPP reductions) + compact-WY factor by the nilpotent product
+//   * potrf_panel_kernel / trsm_block_kernel : blocked Cholesky and triangular solve of the d x d innovation
+// The blocked LQ applies each panel's block reflector I - Y Tf Y^T to the trailing rows with four GEMMs:
+//   G = T[:, panel] + Mt V^T ;  W = G Tf ;  T[:, panel] -= W ;  Mt -= W V.
+// Same algorithm and the same numbers (to rounding) as pnode_dense.hip / pnode_dense_mfma.hip; reference anchors:
+// strategy_filter + correction_ts1 + solver_dynamic (/root/reference/experiments/1_van_der_pol/vdp.py:62-66) on the
+// Brusselator of /root/reference/src/odecheckpts/ivps.py:124-156; arithmetic restated in oracle/pn_oracle.py.
+#include "pnode_device.hpp"
+
+namespace pnode {
+namespace lg {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+#define LG_MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+
+constexpr int PB = 32;  // panel height of the blocked LQ / Cholesky / triangular solve
+
+// ---------------------------------------------------------------------------------------------
+// batched GEMM (row-major): C[b] = beta * C0[b] + alpha * A[b] * op(B[b]);  op(B) = B (K x N) or B^T (B is N x K)
+// M, N, K multiples of 16; all leading dimensions and offsets multiples of 4 doubles.
+// ---------------------------------------------------------------------------------------------
+struct Gemm {
+  const double* A;
+  const double* B;
+  const double* C0;
+  double* C;
+  long sA, sB, sC0, sC;
+  int lda, ldb, ldc0, ldc;
+  int M, N, K;
+  double alpha, beta;
+  const int32_t* act;  // per-trajectory activity flags (nullptr: all)
+  const long* offC;    // optional per-trajectory element offsets of C (replaces b * sC)
+};
+
+template <bool TB, int WMs, int WNs>
+__global__ __launch_bounds__(256) void gemm_kernel(Gemm g) {
+  static_assert(WMs * WNs == 4, "four waves per workgroup");
+  constexpr int BM = 32 * WMs, BN = 32 * WNs, KS = 16, LDAS = KS + 1;
+  constexpr int LDBS = TB ? KS + 1 : BN + 16;
+  constexpr int APASS = BM / 64;
+  __shared__ double As[BM * LDAS];
+  __shared__ double Bs[TB ? BN * LDBS : KS * LDBS];
+  const int b = blockIdx.z;
+  if (g.act && !g.act[b]) return;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, gq = lane >> 4;
+  const int wm = w / WNs, wn = w % WNs;
+  const double* A = g.A + long(b) * g.sA;
+  const double* Bm = g.B + long(b) * g.sB;
+  const double4_t zero4 = {0.0, 0.0, 0.0, 0.0};
+  double4_t acc[2][2] = {{zero4, zero4}, {zero4, zero4}};
+  double4_t ra[APASS], rb;
+  const int lrow = tid >> 2, lc4 = (tid & 3) * 4;               // A tile / transposed B tile: 64 rows x 16 per pass
+  const int nkr = tid / (BN / 4), nc4 = (tid % (BN / 4)) * 4;   // B tile (not transposed): 16 rows x BN
+  auto fetch = [&](int kk) {
+#pragma unroll
+    for (int p = 0; p < APASS; ++p) {
+      const int gr = m0 + p * 64 + lrow;
+      ra[p] = (gr < g.M) ? *reinterpret_cast<const double4_t*>(A + long(gr) * g.lda + kk + lc4) : zero4;
+    }
+    if (TB) {
+      const int gn = n0 + lrow;
+      rb = (lrow < BN && gn < g.N) ? *reinterpret_cast<const double4_t*>(Bm + long(gn) * g.ldb + kk + lc4) : zero4;
+    } else {
+      rb = (nkr < KS && n0 + nc4 < g.N) ? *reinterpret_cast<const double4_t*>(Bm + long(kk + nkr) * g.ldb + n0 + nc4) : zero4;
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int p = 0; p < APASS; ++p)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) As[(p * 64 + lrow) * LDAS + lc4 + q] = ra[p][q];
+    if (TB) {
+      if (lrow < BN)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Bs[lrow * LDBS + lc4 + q] = rb[q];
+    } else if (nkr < KS) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Bs[nkr * LDBS + nc4 + q] = rb[q];
+    }
+  };
+  fetch(0);
+  for (int kk = 0; kk < g.K; kk += KS) {
+    stash();
+    __syncthreads();
+    if (kk + KS < g.K) fetch(kk + KS);
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {
+      double a[2], bb[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        a[t] = As[(wm * 32 + t * 16 + r) * LDAS + k4 * 4 + gq];
+        bb[t] = TB ? Bs[(wn * 32 + t * 16 + r) * LDBS + k4 * 4 + gq] : Bs[(k4 * 4 + gq) * LDBS + wn * 32 + t * 16 + r];
+      }
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) acc[tm][tn] = LG_MFMA(a[tm], bb[tn], acc[tm][tn]);
+    }
+    __syncthreads();
+  }
+  const double* C0 = g.C0 ? g.C0 + long(b) * g.sC0 : nullptr;
+  double* C = g.C + (g.offC ? g.offC[b] : long(b) * g.sC);
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = m0 + wm * 32 + tm * 16 + 4 * q + gq, col = n0 + wn * 32 + tn * 16 + r;
+        if (row < g.M && col < g.N) {
+          double val = g.alpha * acc[tm][tn][q];
+          if (C0) val = fma(g.beta, C0[long(row) * g.ldc0 + col], val);
+          C[long(row) * g.ldc + col] = val;
+        }
+      }
+}
+
+static void gemm(hipStream_t s, int batch, bool transB, const Gemm& g) {
+  if (g.M <= 0 || g.N <= 0 || batch <= 0) return;
+  if (g.N <= 32) {
+    dim3 grid((g.N + 31) / 32, (g.M + 127) / 128, batch);
+    if (transB)
+      hipLaunchKernelGGL((gemm_kernel<true, 4, 1>), grid, dim3(256), 0, s, g);
+    else
+      hipLaunchKernelGGL((gemm_kernel<false, 4, 1>), grid, dim3(256), 0, s, g);
+  } else {
+    dim3 grid((g.N + 63) / 64, (g.M + 63) / 64, batch);
+    if (transB)
+      hipLaunchKernelGGL((gemm_kernel<true, 2, 2>), grid, dim3(256), 0, s, g);
+    else
+      hipLaunchKernelGGL((gemm_kernel<false, 2, 2>), grid, dim3(256), 0, s, g);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LQ panel: rows p0 .. p0+31 of [T | Mt]. 512 threads: 16-lane group rr owns row rr in registers.
+// On exit: Mt rows hold the SCALED reflector rows V (reflector c = [e_c | V_c]), T[p0.., p0..] the final lower block,
+// Tf the 32 x 32 compact-WY factor (row-major) such that the block reflector is I - Y Tf Y^T.
+// ---------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row16_sum(double v) {
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
+  v += dpp_mov<0x141>(v);
+  v += dpp_mov<0x140>(v);
+  return v;
+}
+
+template <int DT>
+__global__ __launch_bounds__(512) void lq_panel_kernel(DenseView v, int p0, double* __restrict__ Tf_out) {
+  constexpr int D = 16 * DT;
+  __shared__ double piv[2][D];
+  __shared__ double Tpp[PB * PB], Gm[PB * PB], Nm[PB * PB], Af[PB * PB];
+  __shared__ double s_tau[PB], s_scl[PB], s_beta[PB];
+  const int b = blockIdx.x;
+  if (!v.act[b]) return;
+  const int tid = threadIdx.x, rr = tid >> 4, ch = tid & 15;
+  double* Mt = v.M + size_t(b) * v.mr_rows * D * D + size_t(p0) * D;
+  double* T = v.R + size_t(b) * v.mr_rows * D * D + size_t(p0) * D + p0;
+  double xr[DT];
+#pragma unroll
+  for (int i = 0; i < DT; ++i) xr[i] = Mt[size_t(rr) * D + ch + 16 * i];
+  for (int e = tid; e < PB * PB; e += 512) {
+    const int i = e >> 5, j = e & 31;
+    Tpp[e] = (j <= i) ? T[size_t(i) * D + j] : 0.0;
+    Gm[e] = 0.0;
+  }
+  if (rr == 0) {
+#pragma unroll
+    for (int i = 0; i < DT; ++i) piv[0][ch + 16 * i] = xr[i];
+  }
+  __syncthreads();
+  for (int c = 0; c < PB; ++c) {
+    const double* pc = piv[c & 1];
+    double p0a = 0.0, p1a = 0.0, d0 = 0.0, d1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < DT; i += 2) {
+      const double x0 = pc[ch + 16 * i], x1 = pc[ch + 16 * (i + 1)];
+      p0a = fma(x0, x0, p0a);
+      p1a = fma(x1, x1, p1a);
+      d0 = fma(xr[i], x0, d0);
+      d1 = fma(xr[i + 1], x1, d1);
+    }
+    const double xx = row16_sum(p0a + p1a);
+    const double dot = row16_sum(d0 + d1);
+    const double alpha = Tpp[c * PB + c];
+    double tauc = 0.0, scale = 0.0, beta = alpha;
+    if (xx != 0.0) {
+      const double nrm2 = fma(alpha, alpha, xx);
+      const double rs = fast_rsqrt(nrm2);
+      const double sgn = copysign(1.0, alpha);
+      beta = -sgn * nrm2 * rs;
+      tauc = fma(fabs(alpha), rs, 1.0);
+      scale = sgn * rs * fast_rcp(tauc);
+    }
+    if (rr > c) {
+      if (tauc != 0.0) {
+        const double tjc = Tpp[rr * PB + c];
+        const double w = tauc * fma(scale, dot, tjc);
+        const double ws = w * scale;
+#pragma unroll
+        for (int i = 0; i < DT; ++i) xr[i] = fma(-ws, pc[ch + 16 * i], xr[i]);
+        if (ch == 0) Tpp[rr * PB + c] = tjc - w;
+      }
+      if (rr == c + 1) {
+        double* pn = piv[(c + 1) & 1];
+#pragma unroll
+        for (int i = 0; i < DT; ++i) pn[ch + 16 * i] = xr[i];
+      }
+    } else if (rr < c) {
+      if (ch == 0) Gm[rr * PB + c] = dot;  // raw rows[rr] . rows[c], both final
+    } else if (ch == 0) {
+      s_beta[c] = beta;
+      s_tau[c] = tauc;
+      s_scl[c] = scale;
+    }
+    __syncthreads();
+  }
+  // scaled reflector rows back to HBM; final diagonal block of T
+  {
+    const double sc = s_scl[rr];
+#pragma unroll
+    for (int i = 0; i < DT; ++i) Mt[size_t(rr) * D + ch + 16 * i] = sc * xr[i];
+  }
+  for (int e = tid; e < PB * PB; e += 512) {
+    const int i = e >> 5, j = e & 31;
+    if (j < i) T[size_t(i) * D + j] = Tpp[e];
+    else if (j == i) T[size_t(i) * D + j] = s_beta[i];
+  }
+  // Tf = (diag(tau)^-1 + striu(Y^T Y))^-1 = (I + N)^-1 diag(tau), N = diag(tau) striu(Y^T Y), nilpotent:
+  // (I + N)^-1 = (I - N)(I + N^2)(I + N^4)(I + N^8)(I + N^16)
+  const int e0 = tid, e1 = tid + 512;
+  {
+    for (int e = tid; e < PB * PB; e += 512) {
+      const int i = e >> 5, j = e & 31;
+      const double nij = (j > i) ? s_tau[i] * s_scl[i] * s_scl[j] * Gm[e] : 0.0;
+      Nm[e] = nij;
+      Af[e] = ((i == j) ? 1.0 : 0.0) - nij;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int it = 0; it < 4; ++it) {
+      double q0 = 0.0, q1 = 0.0;
+      for (int m = 0; m < PB; ++m) {
+        q0 = fma(Nm[(e0 >> 5) * PB + m], Nm[m * PB + (e0 & 31)], q0);
+        q1 = fma(Nm[(e1 >> 5) * PB + m], Nm[m * PB + (e1 & 31)], q1);
+      }
+      __syncthreads();
+      Nm[e0] = q0;
+      Nm[e1] = q1;
+      __syncthreads();
+      double a0 = Af[e0], a1 = Af[e1];
+      for (int m = 0; m < PB; ++m) {
+        a0 = fma(Af[(e0 >> 5) * PB + m], Nm[m * PB + (e0 & 31)], a0);
+        a1 = fma(Af[(e1 >> 5) * PB + m], Nm[m * PB + (e1 & 31)], a1);
+      }
+      __syncthreads();
+      Af[e0] = a0;
+      Af[e1] = a1;
+      __syncthreads();
+    }
+    double* Tfo = Tf_out + size_t(b) * PB * PB;
+    Tfo[e0] = Af[e0] * s_tau[e0 & 31];
+    Tfo[e1] = Af[e1] * s_tau[e1 & 31];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Blocked Cholesky of the d x d matrices S (lower, in place): one panel step = this kernel + one GEMM.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ S, int d, int j0, const int32_t* __restrict__ act) {
+  __shared__ double Ld[PB * (PB + 1)];
+  const int b = blockIdx.x;
+  if (act && !act[b]) return;
+  double* A = S + size_t(b) * d * d;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < PB * PB; e += 256) {
+    const int i = e >> 5, j = e & 31;
+    Ld[i * (PB + 1) + j] = (j <= i) ? A[size_t(j0 + i) * d + j0 + j] : 0.0;
+  }
+  __syncthreads();
+  for (int c = 0; c < PB; ++c) {
+    const double piv = sqrt(Ld[c * (PB + 1) + c]);
+    __syncthreads();
+    if (tid >= c && tid < PB) Ld[tid * (PB + 1) + c] = (tid == c) ? piv : Ld[tid * (PB + 1) + c] / piv;
+    __syncthreads();
+    for (int e = tid; e < PB * PB; e += 256) {
+      const int i = e >> 5, j = e & 31;
+      if (i > c && j > c && j <= i) Ld[i * (PB + 1) + j] -= Ld[i * (PB + 1) + c] * Ld[j * (PB + 1) + c];
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < PB * PB; e += 256) {
+    const int i = e >> 5, j = e & 31;
+    A[size_t(j0 + i) * d + j0 + j] = Ld[i * (PB + 1) + j];  // upper part of the block zeroed
+  }
+  // rows below the block: x <- x Ld^-T
+  for (int row = j0 + PB + tid; row < d; row += 256) {
+    double x[PB];
+    double* ar = A + size_t(row) * d + j0;
+#pragma unroll
+    for (int c = 0; c < PB; ++c) x[c] = ar[c];
+#pragma unroll
+    for (int c = 0; c < PB; ++c) {
+      double acc = x[c];
+#pragma unroll
+      for (int q = 0; q < c; ++q) acc = fma(-x[q], Ld[c * (PB + 1) + q], acc);
+      x[c] = acc / Ld[c * (PB + 1) + c];
+      __builtin_amdgcn_sched_barrier(0);  // keep the LDS operand loads of later columns from being hoisted (spills)
+    }
+#pragma unroll
+    for (int c = 0; c < PB; ++c) ar[c] = x[c];
+  }
+}
+
+// W_ib = C_ii^-1 F_ib for the 32-row block ib of the d x ncols right-hand side F (leading dimension ldf); thread per column
+__global__ __launch_bounds__(256) void trsm_block_kernel(const double* __restrict__ S, double* __restrict__ F, long sF, int ldf,
+                                                         int ncols, int d, int ib, const int32_t* __restrict__ act) {
+  __shared__ double Ld[PB * (PB + 1)];
+  const int b = blockIdx.y;
+  if (act && !act[b]) return;
+  const double* C = S + size_t(b) * d * d;
+  const int tid = threadIdx.x, r0 = ib * PB;
+  for (int e = tid; e < PB * PB; e += 256) {
+    const int i = e >> 5, j = e & 31;
+    Ld[i * (PB + 1) + j] = (j <= i) ? C[size_t(r0 + i) * d + r0 + j] : 0.0;
+  }
+  __syncthreads();
+  const int col = blockIdx.x * 256 + tid;
+  if (col >= ncols) return;
+  double* f = F + long(b) * sF + long(r0) * ldf + col;
+  double x[PB];
+#pragma unroll
+  for (int i = 0; i < PB; ++i) x[i] = f[long(i) * ldf];
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    double acc = x[i];
+#pragma unroll
+    for (int q = 0; q < i; ++q) acc = fma(-Ld[i * (PB + 1) + q], x[q], acc);
+    x[i] = acc / Ld[i * (PB + 1) + i];
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int i = 0; i < PB; ++i) f[long(i) * ldf] = x[i];
+}
+
+__device__ __forceinline__ void precond(int n, double dt, const IwpConst& K, double* p, double* pinv) {
+  const double adt = fabs(dt);
+  double pw = sqrt(adt);
+  for (int i = n - 1; i >= 0; --i) {
+    p[i] = pw / K.fact[i];
+    pinv[i] = K.fact[i] / pw;
+    pw *= adt;
+  }
+}
+
+__device__ __forceinline__ double block_sum256(double val, double* red) {
+  val = wave_sum(val);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = val;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// x <- C^-1 x (lower C, d x d, global), whole workgroup
+__device__ void forward_vec(const double* C, int d, double* x) {
+  for (int a = 0; a < d; ++a) {
+    __syncthreads();
+    const double xa = x[a] / C[size_t(a) * d + a];
+    __syncthreads();
+    if (threadIdx.x == 0) x[a] = xa;
+    for (int r = a + 1 + threadIdx.x; r < d; r += 256) x[r] -= C[size_t(r) * d + a] * xa;
+  }
+  __syncthreads();
+}
+
+// begin, part 1: activity flags, m^-, f, J, z, and F1 = [B_0 .. B_k] (d x (k+1)d, leading dimension D, into v.X) with
+// B_j = lq[k][j] I - sum_{i<k} lq[i][j] J_i, so that S1 = F1 F1^T; diag(S1) -> v.err
+__global__ __launch_bounds__(256) void begin_a_kernel(DenseView v, const StepArg* __restrict__ args, const IwpConst* __restrict__ Kc) {
+  extern __shared__ double smem[];
+  const int b = blockIdx.x;
+  const StepArg arg = args[b];
+  if (threadIdx.x == 0) {
+    v.act[b] = arg.active ? 1 : 0;
+    v.lgOff[b] = (long(arg.dst) * v.B + b) * long(v.D) * v.D;
+  }
+  if (!arg.active) return;
+  const IwpConst& K = *Kc;
+  const int d = v.d, k = v.k, n = v.n, kd = k * d, D = v.D;
+  double* ybuf = smem;     // [k][d]
+  double* lq = ybuf + kd;  // [n][n]
+  double p[kMaxN], pinv[kMaxN];
+  precond(n, arg.dt, K, p, pinv);
+  for (int idx = threadIdx.x; idx < n * n; idx += 256) {
+    const int i = idx / n, j = idx % n;
+    lq[idx] = (j <= i) ? p[i] * K.qsT[j][i] : 0.0;
+  }
+  const size_t sB = size_t(v.B);
+  const double* msrc = v.mean + (size_t(arg.src) * sB + b) * n * d;
+  double* mdst = v.mean + (size_t(arg.dst) * sB + b) * n * d;
+  for (int j = threadIdx.x; j < d; j += 256)
+    for (int i = 0; i < n; ++i) {
+      double acc = 0.0;
+      for (int kk = i; kk < n; ++kk) acc += K.a[i][kk] * pinv[kk] * msrc[kk * d + j];
+      const double e = p[i] * acc;
+      mdst[i * d + j] = e;
+      if (i < k) ybuf[i * d + j] = e;
+    }
+  __syncthreads();
+  VfCtx ctx{v.vf_id, d, k, v.prm ? v.prm + (v.prm_per_traj ? size_t(b) * v.P : 0) : nullptr,
+            v.user_f ? v.user_f + size_t(b) * d : nullptr, v.user_J ? v.user_J + size_t(b) * d * k * d : nullptr};
+  const double tnew = arg.t + arg.dt;
+  for (int j = threadIdx.x; j < d; j += 256) v.z[size_t(b) * d + j] = mdst[k * d + j] - vf_f(ctx, ybuf, j, tnew);
+  double* Jg = v.J + size_t(b) * d * kd;
+  for (int idx = threadIdx.x; idx < d * kd; idx += 256) {
+    const int a = idx / kd, rest = idx % kd;
+    Jg[idx] = vf_jac(ctx, ybuf, a, rest / d, rest % d, tnew);
+  }
+  __syncthreads();
+  double* F1 = v.X + size_t(b) * d * D;
+  for (int idx = threadIdx.x; idx < d * (k + 1) * d; idx += 256) {
+    const int a = idx / ((k + 1) * d), rest = idx % ((k + 1) * d);
+    const int j = rest / d, c = rest % d;
+    double val = (a == c) ? lq[k * n + j] : 0.0;
+    for (int i = 0; i < k; ++i) val -= lq[i * n + j] * Jg[a * kd + i * d + c];
+    F1[size_t(a) * D + rest] = val;
+  }
+  __syncthreads();
+  for (int a = threadIdx.x; a < d; a += 256) {
+    double acc = 0.0;
+    for (int c = 0; c < (k + 1) * d; ++c) acc = fma(F1[size_t(a) * D + c], F1[size_t(a) * D + c], acc);
+    v.err[size_t(b) * d + a] = acc;
+  }
+}
+
+// begin, part 2 (after S1 = C C^T): sigma_hat^2 = |C^-1 z|^2 / d, err = dt sigma_hat sqrt(diag S1)
+__global__ __launch_bounds__(256) void begin_c_kernel(DenseView v, const StepArg* __restrict__ args, double* __restrict__ wbuf) {
+  __shared__ double red[4];
+  const int b = blockIdx.x;
+  const StepArg arg = args[b];
+  if (!arg.active) return;
+  const int d = v.d;
+  double* x = wbuf + size_t(b) * d;
+  for (int j = threadIdx.x; j < d; j += 256) x[j] = v.z[size_t(b) * d + j];
+  forward_vec(v.S + size_t(b) * d * d, d, x);
+  double part = 0.0;
+  for (int j = threadIdx.x; j < d; j += 256) part += x[j] * x[j];
+  const double ww = block_sum256(part, red);
+  const double sigma_hat = sqrt(ww / double(d));
+  double* errg = v.err + size_t(b) * d;
+  for (int j = threadIdx.x; j < d; j += 256) errg[j] = arg.dt * sigma_hat * sqrt(errg[j]);
+  if (threadIdx.x == 0) v.sig_new[b] = v.dynamic ? sigma_hat : v.sigma[size_t(arg.src) * v.B + b];
+}
+
+// L^- = diag(p) T (lower; zeros above the diagonal) into v.M (Mt is dead after the LQ): regular batch stride for the GEMMs
+__global__ __launch_bounds__(256) void scale_t_kernel(DenseView v, const StepArg* __restrict__ args, const IwpConst* __restrict__ Kc) {
+  const int b = blockIdx.y;
+  const StepArg arg = args[b];
+  if (!arg.active) return;
+  const int D = v.D, d = v.d;
+  double p[kMaxN], pinv[kMaxN];
+  precond(v.n, arg.dt, *Kc, p, pinv);
+  const double* T = v.R + size_t(b) * v.mr_rows * D * D;
+  double* L = v.M + size_t(b) * v.mr_rows * D * D;
+  for (int r = blockIdx.x; r < D; r += gridDim.x) {
+    const double pr = p[r / d];
+    for (int c = threadIdx.x; c < D; c += 256) L[size_t(r) * D + c] = (c <= r) ? pr * T[size_t(r) * D + c] : 0.0;
+  }
+}
+
+// wz = C^-1 z (in place in v.z)
+__global__ __launch_bounds__(256) void solve_wz_kernel(DenseView v, const StepArg* __restrict__ args) {
+  const int b = blockIdx.x;
+  if (!args[b].active) return;
+  forward_vec(v.S + size_t(b) * v.d * v.d, v.d, v.z + size_t(b) * v.d);
+}
+
+// m = m^- - Y wz ; normalised error norm ; output scale of the new state
+__global__ __launch_bounds__(256) void finish_kernel(DenseView v, const StepArg* __restrict__ args) {
+  __shared__ double red[4];
+  const int b = blockIdx.x;
+  const StepArg arg = args[b];
+  if (!arg.active) return;
+  const int d = v.d, D = v.D;
+  const size_t sB = size_t(v.B);
+  double* mdst = v.mean + (size_t(arg.dst) * sB + b) * D;
+  const double* Y = v.Ft + size_t(b) * D * d;
+  const double* wz = v.z + size_t(b) * d;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int r = wv; r < D; r += 4) {
+    double acc = 0.0;
+    for (int a = lane; a < d; a += kWave) acc = fma(Y[size_t(r) * d + a], wz[a], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) mdst[r] -= acc;
+  }
+  __syncthreads();
+  const double atol = v.atol[b], rtol = v.rtol[b];
+  double part = 0.0;
+  for (int j = threadIdx.x; j < d; j += 256) {
+    const double rel = v.err[size_t(b) * d + j] / (atol + rtol * fabs(mdst[j]));
+    part += rel * rel;
+  }
+  const double tot = block_sum256(part, red);
+  if (threadIdx.x == 0) {
+    v.errnorm[b] = sqrt(tot / double(d));
+    v.sigma[size_t(arg.dst) * sB + b] = v.sig_new[b];
+  }
+}
+
+static void potrf(hipStream_t s, const DenseView& v) {
+  const int d = v.d;
+  for (int j0 = 0; j0 < d; j0 += PB) {
+    hipLaunchKernelGGL(potrf_panel_kernel, dim3(v.B), dim3(256), 0, s, v.S, d, j0, v.act);
+    const int rem = d - j0 - PB;
+    if (rem > 0) {
+      double* sub = v.S + size_t(j0 + PB) * d + j0;  // rows below, panel columns
+      Gemm g{sub, sub, v.S + size_t(j0 + PB) * d + j0 + PB, v.S + size_t(j0 + PB) * d + j0 + PB,
+             long(d) * d, long(d) * d, long(d) * d, long(d) * d, d, d, d, d, rem, rem, PB, -1.0, 1.0, v.act, nullptr};
+      gemm(s, v.B, true, g);
+    }
+  }
+}
+
+template <int DT>
+static void launch_panel(const DenseView& v, int p0, double* Tf, hipStream_t s) {
+  hipLaunchKernelGGL(lq_panel_kernel<DT>, dim3(v.B), dim3(512), 0, s, v, p0, Tf);
+}
+
+}  // namespace lg
+
+bool dense_large_supported(const DenseView& v) {
+  const int DT = v.D / 16;
+  return v.ts1 && !v.fixedpoint && v.d % 32 == 0 && v.D % 32 == 0 && (DT == 8 || DT == 16 || DT == 32 || DT == 48 || DT == 64) &&
+         v.lgG != nullptr;
+}
+
+void dense_large_launch_step(const DenseView& v, const StepArg* args, const IwpConst* K, hipStream_t s, const PhaseEvents* ev) {
+  using namespace lg;
+  auto mark = [&](int i) {
+    if (ev) (void)hipEventRecord(ev->ev[i], s);
+  };
+  const int B = v.B, d = v.d, k = v.k, D = v.D, kd = k * d;
+  const long sDD = long(v.mr_rows) * D * D;
+  // ---- begin
+  const size_t shm_a = (size_t(kd) + size_t(v.n) * v.n) * sizeof(double);
+  hipLaunchKernelGGL(begin_a_kernel, dim3(B), dim3(256), shm_a, s, v, args, K);
+  {
+    Gemm g{v.X, v.X, nullptr, v.S, long(d) * D, long(d) * D, 0, long(d) * d, D, D, 0, d, d, d, (k + 1) * d, 1.0, 0.0, v.act, nullptr};
+    gemm(s, B, true, g);
+  }
+  potrf(s, v);
+  hipLaunchKernelGGL(begin_c_kernel, dim3(B), dim3(256), 0, s, v, args, v.lgW);
+  mark(1);
+  // ---- time update: blocked row-Householder LQ of [T | Mt]
+  dense_launch_lq_input(v, args, K, s);
+  mark(2);
+  const int rows_total = v.mr_rows * D;  // == D (filter)
+  for (int p0 = 0; p0 < D; p0 += PB) {
+    switch (D / 16) {
+      case 8: launch_panel<8>(v, p0, v.lgTf, s); break;
+      case 16: launch_panel<16>(v, p0, v.lgTf, s); break;
+      case 32: launch_panel<32>(v, p0, v.lgTf, s); break;
+      case 48: launch_panel<48>(v, p0, v.lgTf, s); break;
+      default: launch_panel<64>(v, p0, v.lgTf, s); break;
+    }
+    const int j0 = p0 + PB, rows = rows_total - j0;
+    if (rows <= 0) break;
+    double* Mb = v.M + size_t(j0) * D;         // trailing rows of Mt
+    double* Vp = v.M + size_t(p0) * D;         // scaled reflector rows (32 x D)
+    double* Tb = v.R + size_t(j0) * D + p0;    // trailing rows of T, panel columns
+    const long sG = long(rows_total) * PB;
+    Gemm g1{Mb, Vp, Tb, v.lgG, sDD, sDD, sDD, sG, D, D, D, PB, rows, PB, D, 1.0, 1.0, v.act, nullptr};
+    gemm(s, B, true, g1);  // G = T[:, panel] + Mt V^T
+    Gemm g2{v.lgG, v.lgTf, nullptr, v.lgW, sG, long(PB) * PB, 0, sG, PB, PB, 0, PB, rows, PB, PB, 1.0, 0.0, v.act, nullptr};
+    gemm(s, B, false, g2);  // W = G Tf
+    Gemm g3{v.lgG, v.lgTf, Tb, Tb, sG, long(PB) * PB, sDD, sDD, PB, PB, D, D, rows, PB, PB, -1.0, 1.0, v.act, nullptr};
+    gemm(s, B, false, g3);  // T[:, panel] -= G Tf
+    Gemm g4{v.lgW, Vp, Mb, Mb, sG, sDD, sDD, sDD, PB, D, D, D, rows, D, PB, -1.0, 1.0, v.act, nullptr};
+    gemm(s, B, false, g4);  // Mt -= W V
+  }
+  mark(3);
+  // ---- measurement update (projector form)
+  hipLaunchKernelGGL(scale_t_kernel, dim3(64, B), dim3(256), 0, s, v, args, K);
+  {  // F = L^-[k-block rows] - J L^-[0:kd rows]      (d x D)
+    Gemm f{v.J, v.M, v.M + size_t(kd) * D, v.X, long(d) * kd, sDD, sDD, long(d) * D, kd, D, D, D, d, D, kd, -1.0, 1.0, v.act, nullptr};
+    gemm(s, B, false, f);
+  }
+  {
+    Gemm g{v.X, v.X, nullptr, v.S, long(d) * D, long(d) * D, 0, long(d) * d, D, D, 0, d, d, d, D, 1.0, 0.0, v.act, nullptr};
+    gemm(s, B, true, g);  // S = F F^T
+  }
+  potrf(s, v);
+  hipLaunchKernelGGL(solve_wz_kernel, dim3(B), dim3(256), 0, s, v, args);
+  for (int ib = 0; ib < d / PB; ++ib) {  // W = C^-1 F, right-looking blocked forward substitution
+    hipLaunchKernelGGL(trsm_block_kernel, dim3((D + 255) / 256, B), dim3(256), 0, s, v.S, v.X, long(d) * D, D, D, d, ib, v.act);
+    const int rem = d - (ib + 1) * PB;
+    if (rem > 0) {
+      Gemm g{v.S + size_t(ib + 1) * PB * d + ib * PB, v.X + size_t(ib) * PB * D, v.X + size_t(ib + 1) * PB * D,
+             v.X + size_t(ib + 1) * PB * D, long(d) * d, long(d) * D, long(d) * D, long(d) * D, d, D, D, D, rem, D, PB, -1.0, 1.0,
+             v.act, nullptr};
+      gemm(s, B, false, g);
+    }
+  }
+  {
+    Gemm y{v.M, v.X, nullptr, v.Ft, sDD, long(d) * D, 0, long(D) * d, D, D, 0, d, D, d, D, 1.0, 0.0, v.act, nullptr};
+    gemm(s, B, true, y);  // Y = L^- W^T   (D x d)
+    // L = L^- - Y W, written to each trajectory's destination slot (per-trajectory offsets)
+    Gemm u{v.Ft, v.X, v.M, v.U, long(D) * d, long(d) * D, sDD, 0, d, D, D, D, D, D, d, -1.0, 1.0, v.act, v.lgOff};
+    gemm(s, B, false, u);
+  }
+  hipLaunchKernelGGL(finish_kernel, dim3(B), dim3(256), 0, s, v, args);
+  mark(4);
+}
+
+}  // namespace pnode

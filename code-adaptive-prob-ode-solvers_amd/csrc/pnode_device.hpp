@@ -70,6 +70,12 @@ struct DenseView {
   double* ck_G;     // [B][K][D][D]
   double* ck_xi;    // [B][K][D]
   double* ck_Lam;   // [B][K][D][D]
+  // large-D path (pnode_dense_large.hip): panel scratch of the blocked LQ and per-trajectory output offsets
+  int force_large;  // 1: take the large-D path whenever it supports the shape (A/B testing at small D)
+  double* lgG;      // [B][mr_rows*D][32]
+  double* lgW;      // [B][mr_rows*D][32]
+  double* lgTf;     // [B][32][32]
+  long* lgOff;      // [B]
 };
 
 // Optional per-phase timing of one dense step: events[0..4] bracket begin | lq_input | lq | correct.
@@ -89,6 +95,10 @@ void dense_fp_launch_interp(const DenseView& v, const InterpArg* iargs, const Fp
                             hipStream_t s);
 void dense_fp_launch_smooth(const DenseView& v, const int32_t* num_filled, double* out, hipStream_t s);
 void dense_launch_lq_generic(const DenseView& v, int rows_total, hipStream_t s);
+void dense_launch_lq_input(const DenseView& v, const StepArg* args, const IwpConst* K, hipStream_t s);
+// large-D path (pnode_dense_large.hip): batched MFMA GEMMs + blocked LQ / Cholesky / triangular solve through HBM
+bool dense_large_supported(const DenseView& v);
+void dense_large_launch_step(const DenseView& v, const StepArg* args, const IwpConst* K, hipStream_t s, const PhaseEvents* ev);
 // small-D fused path (pnode_dense_small.hip): one wavefront per trajectory, one kernel per attempt
 bool dense_small_supported(const DenseView& v);
 void dense_small_launch_step(const DenseView& v, const StepArg* args, const IwpConst* K, hipStream_t s);

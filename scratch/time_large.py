@@ -1,0 +1,33 @@
+"""Step time of the dense paths at large D (Brusselator N, nu=3)."""
+import sys, time, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "code-adaptive-prob-ode-solvers_amd")); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np
+from probdiffeq_hip import _backend, vector_fields as V
+from helpers import tcoeffs, brusselator_y0
+
+def run(N, nu, B, path, steps=5):
+    vf = V.brusselator(N)
+    y0 = np.stack([brusselator_y0(N, 0.1 * b) for b in range(B)])
+    tc = np.stack(tcoeffs(vf, [y0], nu), axis=1)
+    bt = _backend.Batch(batch=B, d=vf.d, nu=nu, ode_order=1, model="dense", correction="ts1", strategy="filter",
+                        calibration="dynamic", vf_id=vf.vf_id, vf_params=vf.param_array(), num_checkpoints=1)
+    if path: bt.set_generic_path(path)
+    bt.set_initial(tc, np.zeros(B), np.ones(B)); bt.set_tolerances(1e-6, 1e-6)
+    err = np.zeros(B); one = np.ones(B, np.uint8)
+    bt.attempt_step(np.full(B, 0.005), one, err); bt.commit(one)
+    bt.set_phase_timing(True)
+    t0 = time.perf_counter()
+    ph = np.zeros(4)
+    for _ in range(steps):
+        bt.attempt_step(np.full(B, 0.005), one, err); bt.commit(one)
+        ph += np.array(bt.last_phase_ms())
+    dt = (time.perf_counter() - t0) / steps
+    print(f"N={N} D={(nu+1)*2*N} B={B} path={path}: {dt*1e3:.2f} ms/step  phases(begin,lq_in,lq,correct)={np.round(ph/steps,3)}  err0={err[0]:.6e}", flush=True)
+    bt.close()
+
+if __name__ == "__main__":
+    run(32, 3, 256, 0); run(32, 3, 256, 2)
+    run(64, 3, 64, 2)
+    run(128, 3, 64, 2)
+    run(128, 3, 2, 1, steps=1)

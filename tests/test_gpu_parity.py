@@ -259,9 +259,62 @@ def test_dense_mfma_path_matches_oracle_and_generic(hip_lib, N, nu):
     slow.close()
 
 
+@pytest.mark.parametrize("N,nu", [(16, 3), (32, 3), (64, 3)])
+def test_dense_large_path_matches_oracle_and_mfma_path(hip_lib, N, nu):
+    """The HBM-tiled large-D kernels (batched MFMA GEMMs, blocked LQ / Cholesky / triangular solve; the path BASELINE
+    config 5 takes at D = 1024) forced at sizes the oracle steps through quickly: several steps with per-trajectory
+    step sizes, a rejected step (destination slots drift apart) and an inactive trajectory, against the oracle and the
+    default path."""
+    vf = V.brusselator(N)
+    B = 3
+    y0 = np.stack([brusselator_y0(N, ph) for ph in (0.0, 0.4, 1.1)])
+    tc = tcoeffs(vf, [y0], nu)
+    tc_arr = np.stack(tc, axis=1)
+    large = _dense_batch(vf, nu, "ts1", B)
+    large.set_generic_path(2)
+    ref = _dense_batch(vf, nu, "ts1", B)
+    for bt in (large, ref):
+        bt.set_initial(tc_arr, np.zeros(B), np.ones(B))
+        bt.set_tolerances(1e-5, 1e-5)
+    cfg = po.SolverConfig(nu=nu, model="dense", correction="ts1", strategy="filter", calibration="dynamic")
+    acfg = po.AdaptiveConfig(1e-5, 1e-5)
+    prob = oracle_problem(vf)
+    states = [po.initial_state(cfg, [c[b] for c in tc], 0.0) for b in range(B)]
+    el, er = np.zeros(B), np.zeros(B)
+    plan = [(0.01, [1, 1, 1], [1, 1, 1]), (0.02, [1, 1, 1], [1, 0, 1]), (0.015, [1, 1, 0], [1, 1, 0]), (0.03, [1, 1, 1], [1, 1, 1])]
+    for it, (dt0, active, accept) in enumerate(plan):
+        dts = dt0 * (1.0 + 0.2 * np.arange(B))
+        act = np.array(active, np.uint8)
+        acc = np.array(accept, np.uint8)
+        large.attempt_step(dts, act, el)
+        ref.attempt_step(dts, act, er)
+        large.commit(acc)
+        ref.commit(acc)
+        ml, mr = large.read_mean(0), ref.read_mean(0)
+        Rl = large.read_factor(0)
+        for b in range(B):
+            if not active[b]:
+                continue
+            e, new = po.step(cfg, prob, states[b], float(dts[b]))
+            en = po.normalise_error(acfg, e, new.mean[0], states[b].mean[0])
+            assert abs(el[b] - en) <= 1e-7 * en, (it, b, el[b], en)
+            assert abs(el[b] - er[b]) <= 1e-7 * en
+            if not accept[b]:
+                continue
+            for i in range(nu + 1):
+                tol_i = 1e-11 if i == 0 else (1e-9 if i == 1 else (1e-6 if nu <= 4 else 1e-4))
+                assert relmax(ml[b, i], new.mean[i]) < tol_i, (it, b, i)
+                assert relmax(ml[b, i], mr[b, i]) < tol_i, (it, b, i)
+            # nu = 7: the covariance spans 20 orders of magnitude; the comparison is conditioning-limited
+            assert relmax(Rl[b].T @ Rl[b], new.chol @ new.chol.T) < (1e-7 if nu <= 4 else 1e-5), (it, b)
+            states[b] = new
+    large.close()
+    ref.close()
+
+
 def test_dense_maximum_size_generic_path(hip_lib):
-    """BASELINE config 5 size (Brusselator N=128: d=256, D=1024) and an un-instantiated tile count (N=64, nu=4:
-    D=640) run on the generic dense kernels; two steps against the oracle."""
+    """BASELINE config 5 size (Brusselator N=128: d=256, D=1024; default: the large-D path) and an un-instantiated tile
+    count (N=64, nu=4: D=640, generic dense kernels); two steps against the oracle."""
     for N, nu in ((128, 3), (64, 4)):
         vf = V.brusselator(N)
         tc = tcoeffs(vf, [brusselator_y0(N)[None]], nu)
