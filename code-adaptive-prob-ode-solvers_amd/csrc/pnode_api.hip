@@ -318,9 +318,11 @@ int pnode_create(const pnode_config* cfg, pnode_batch** out) {
     {
       const int DT = int(D) / 16;
       if (v.ts1 && !v.fixedpoint && d % 32 == 0 && (DT == 8 || DT == 16 || DT == 32 || DT == 48 || DT == 64)) {
-        ALLOC(v.lgG, B * v.mr_rows * D * 32);
-        ALLOC(v.lgW, B * v.mr_rows * D * 32);
-        ALLOC(v.lgTf, B * 32 * 32);
+        ALLOC(v.lgG, B * v.mr_rows * D * 128);
+        ALLOC(v.lgW, B * v.mr_rows * D * 128);
+        ALLOC(v.lgTf, B * 4 * 32 * 32);
+        ALLOC(v.lgGram, B * 128 * 128);
+        ALLOC(v.lgTfo, B * 128 * 128);
         ALLOC(v.lgOff, B);
       }
     }

@@ -159,43 +159,53 @@ __device__ __forceinline__ double row16_sum(double v) {
   return v;
 }
 
+// Sum over the wavefront, result uniform: DPP within the 16-lane rows, v_readlane across them.
+__device__ __forceinline__ double wave_total(double v) {
+  v = row16_sum(v);
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  double s = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+  s += __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+  s += __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+  s += __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+  return s;
+}
+
+// 1024 threads: wavefront w owns rows 2w, 2w+1 (lane <-> columns lane + 64 i), so the pivot row is read from LDS once
+// per step and serves the norm, both dot products and both updates out of registers.
 template <int DT>
-__global__ __launch_bounds__(512) void lq_panel_kernel(DenseView v, int p0, double* __restrict__ Tf_out) {
-  constexpr int D = 16 * DT;
+__global__ __launch_bounds__(1024) void lq_panel_kernel(DenseView v, int p0, double* __restrict__ Tf_out, int tf_stride) {
+  constexpr int D = 16 * DT, NC = DT / 4;
   __shared__ double piv[2][D];
   __shared__ double Tpp[PB * PB], Gm[PB * PB], Nm[PB * PB], Af[PB * PB];
   __shared__ double s_tau[PB], s_scl[PB], s_beta[PB];
   const int b = blockIdx.x;
   if (!v.act[b]) return;
-  const int tid = threadIdx.x, rr = tid >> 4, ch = tid & 15;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int r0 = 2 * w, r1 = 2 * w + 1;
   double* Mt = v.M + size_t(b) * v.mr_rows * D * D + size_t(p0) * D;
   double* T = v.R + size_t(b) * v.mr_rows * D * D + size_t(p0) * D + p0;
-  double xr[DT];
+  double x0[NC], x1[NC];
 #pragma unroll
-  for (int i = 0; i < DT; ++i) xr[i] = Mt[size_t(rr) * D + ch + 16 * i];
-  for (int e = tid; e < PB * PB; e += 512) {
-    const int i = e >> 5, j = e & 31;
-    Tpp[e] = (j <= i) ? T[size_t(i) * D + j] : 0.0;
-    Gm[e] = 0.0;
+  for (int i = 0; i < NC; ++i) {
+    x0[i] = Mt[size_t(r0) * D + lane + 64 * i];
+    x1[i] = Mt[size_t(r1) * D + lane + 64 * i];
   }
-  if (rr == 0) {
-#pragma unroll
-    for (int i = 0; i < DT; ++i) piv[0][ch + 16 * i] = xr[i];
+  {
+    const int i = tid >> 5, j = tid & 31;
+    Tpp[tid] = (j <= i) ? T[size_t(i) * D + j] : 0.0;
+    Gm[tid] = 0.0;
   }
-  __syncthreads();
-  for (int c = 0; c < PB; ++c) {
-    const double* pc = piv[c & 1];
-    double p0a = 0.0, p1a = 0.0, d0 = 0.0, d1 = 0.0;
+  // The owner of the next pivot row computes its Householder scalars and publishes them with the row, so the other
+  // fifteen wavefronts spend their issue slots on the two dot products and the two row updates only.
+  auto publish = [&](int c, const double (&x)[NC]) {
+    double* pn = piv[c & 1];
+    double pp = 0.0;
 #pragma unroll
-    for (int i = 0; i < DT; i += 2) {
-      const double x0 = pc[ch + 16 * i], x1 = pc[ch + 16 * (i + 1)];
-      p0a = fma(x0, x0, p0a);
-      p1a = fma(x1, x1, p1a);
-      d0 = fma(xr[i], x0, d0);
-      d1 = fma(xr[i + 1], x1, d1);
+    for (int i = 0; i < NC; ++i) {
+      pn[lane + 64 * i] = x[i];
+      pp = fma(x[i], x[i], pp);
     }
-    const double xx = row16_sum(p0a + p1a);
-    const double dot = row16_sum(d0 + d1);
+    const double xx = wave_total(pp);
     const double alpha = Tpp[c * PB + c];
     double tauc = 0.0, scale = 0.0, beta = alpha;
     if (xx != 0.0) {
@@ -206,76 +216,151 @@ __global__ __launch_bounds__(512) void lq_panel_kernel(DenseView v, int p0, doub
       tauc = fma(fabs(alpha), rs, 1.0);
       scale = sgn * rs * fast_rcp(tauc);
     }
-    if (rr > c) {
-      if (tauc != 0.0) {
-        const double tjc = Tpp[rr * PB + c];
-        const double w = tauc * fma(scale, dot, tjc);
-        const double ws = w * scale;
-#pragma unroll
-        for (int i = 0; i < DT; ++i) xr[i] = fma(-ws, pc[ch + 16 * i], xr[i]);
-        if (ch == 0) Tpp[rr * PB + c] = tjc - w;
-      }
-      if (rr == c + 1) {
-        double* pn = piv[(c + 1) & 1];
-#pragma unroll
-        for (int i = 0; i < DT; ++i) pn[ch + 16 * i] = xr[i];
-      }
-    } else if (rr < c) {
-      if (ch == 0) Gm[rr * PB + c] = dot;  // raw rows[rr] . rows[c], both final
-    } else if (ch == 0) {
+    if (lane == 0) {
       s_beta[c] = beta;
       s_tau[c] = tauc;
       s_scl[c] = scale;
+    }
+  };
+  __syncthreads();
+  if (w == 0) publish(0, x0);
+  __syncthreads();
+  for (int c = 0; c < ((v.ablate & 1) ? 0 : PB); ++c) {
+    const double* pc = piv[c & 1];
+    double xc[NC];
+    double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      xc[i] = pc[lane + 64 * i];
+      d0 = fma(x0[i], xc[i], d0);
+      d1 = fma(x1[i], xc[i], d1);
+    }
+    const double dot0 = wave_total(d0);
+    const double dot1 = wave_total(d1);
+    const double tauc = s_tau[c], scale = s_scl[c];
+    if (r0 > c) {
+      if (tauc != 0.0) {
+        const double tjc = Tpp[r0 * PB + c];
+        const double wv = tauc * fma(scale, dot0, tjc);
+        const double ws = wv * scale;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) x0[i] = fma(-ws, xc[i], x0[i]);
+        if (lane == 0) Tpp[r0 * PB + c] = tjc - wv;
+      }
+    } else if (r0 < c) {
+      if (lane == 0) Gm[r0 * PB + c] = dot0;  // raw rows[r0] . rows[c], both final
+    }
+    if (r1 > c) {
+      if (tauc != 0.0) {
+        const double tjc = Tpp[r1 * PB + c];
+        const double wv = tauc * fma(scale, dot1, tjc);
+        const double ws = wv * scale;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) x1[i] = fma(-ws, xc[i], x1[i]);
+        if (lane == 0) Tpp[r1 * PB + c] = tjc - wv;
+      }
+    } else if (r1 < c) {
+      if (lane == 0) Gm[r1 * PB + c] = dot1;
+    }
+    if (c + 1 < PB && ((c + 1) >> 1) == w) {  // the next pivot row has received its last update
+      if ((c + 1) & 1) publish(c + 1, x1);
+      else publish(c + 1, x0);
     }
     __syncthreads();
   }
   // scaled reflector rows back to HBM; final diagonal block of T
   {
-    const double sc = s_scl[rr];
+    const double sc0 = s_scl[r0], sc1 = s_scl[r1];
 #pragma unroll
-    for (int i = 0; i < DT; ++i) Mt[size_t(rr) * D + ch + 16 * i] = sc * xr[i];
-  }
-  for (int e = tid; e < PB * PB; e += 512) {
-    const int i = e >> 5, j = e & 31;
-    if (j < i) T[size_t(i) * D + j] = Tpp[e];
-    else if (j == i) T[size_t(i) * D + j] = s_beta[i];
-  }
-  // Tf = (diag(tau)^-1 + striu(Y^T Y))^-1 = (I + N)^-1 diag(tau), N = diag(tau) striu(Y^T Y), nilpotent:
-  // (I + N)^-1 = (I - N)(I + N^2)(I + N^4)(I + N^8)(I + N^16)
-  const int e0 = tid, e1 = tid + 512;
-  {
-    for (int e = tid; e < PB * PB; e += 512) {
-      const int i = e >> 5, j = e & 31;
-      const double nij = (j > i) ? s_tau[i] * s_scl[i] * s_scl[j] * Gm[e] : 0.0;
-      Nm[e] = nij;
-      Af[e] = ((i == j) ? 1.0 : 0.0) - nij;
+    for (int i = 0; i < NC; ++i) {
+      Mt[size_t(r0) * D + lane + 64 * i] = sc0 * x0[i];
+      Mt[size_t(r1) * D + lane + 64 * i] = sc1 * x1[i];
     }
+  }
+  const int ei = tid >> 5, ej = tid & 31;
+  if (ej < ei) T[size_t(ei) * D + ej] = Tpp[tid];
+  else if (ej == ei) T[size_t(ei) * D + ej] = s_beta[ei];
+  // Tf = (diag(tau)^-1 + striu(Y^T Y))^-1 = (I + N)^-1 diag(tau), N = diag(tau) striu(Y^T Y), nilpotent:
+  // (I + N)^-1 = (I - N)(I + N^2)(I + N^4)(I + N^8)(I + N^16); one entry per thread
+  {
+    const double nij = (ej > ei) ? s_tau[ei] * s_scl[ei] * s_scl[ej] * Gm[tid] : 0.0;
+    Nm[tid] = nij;
+    Af[tid] = ((ei == ej) ? 1.0 : 0.0) - nij;
     __syncthreads();
 #pragma unroll 1
-    for (int it = 0; it < 4; ++it) {
-      double q0 = 0.0, q1 = 0.0;
-      for (int m = 0; m < PB; ++m) {
-        q0 = fma(Nm[(e0 >> 5) * PB + m], Nm[m * PB + (e0 & 31)], q0);
-        q1 = fma(Nm[(e1 >> 5) * PB + m], Nm[m * PB + (e1 & 31)], q1);
-      }
+    for (int it = 0; it < ((v.ablate & 2) ? 0 : 4); ++it) {
+      double q = 0.0;
+#pragma unroll 8
+      for (int m = 0; m < PB; ++m) q = fma(Nm[ei * PB + m], Nm[m * PB + ej], q);
       __syncthreads();
-      Nm[e0] = q0;
-      Nm[e1] = q1;
+      Nm[tid] = q;
       __syncthreads();
-      double a0 = Af[e0], a1 = Af[e1];
-      for (int m = 0; m < PB; ++m) {
-        a0 = fma(Af[(e0 >> 5) * PB + m], Nm[m * PB + (e0 & 31)], a0);
-        a1 = fma(Af[(e1 >> 5) * PB + m], Nm[m * PB + (e1 & 31)], a1);
-      }
+      double a = Af[tid];
+#pragma unroll 8
+      for (int m = 0; m < PB; ++m) a = fma(Af[ei * PB + m], Nm[m * PB + ej], a);
       __syncthreads();
-      Af[e0] = a0;
-      Af[e1] = a1;
+      Af[tid] = a;
       __syncthreads();
     }
-    double* Tfo = Tf_out + size_t(b) * PB * PB;
-    Tfo[e0] = Af[e0] * s_tau[e0 & 31];
-    Tfo[e1] = Af[e1] * s_tau[e1 & 31];
+    Tf_out[size_t(b) * tf_stride + tid] = Af[tid] * s_tau[ej];
   }
+}
+
+// Compact-WY factor of an outer block of nb 32-row panels from the panel factors (diagonal blocks) and the Gram matrix
+// of the scaled reflector rows: Tf^-1 = diag-blocks(Tf_p^-1) + striu-blocks(V V^T), inverted by block back-substitution
+//      X_ii = Tf_i ,   X_ij = -Tf_i sum_{l=i+1..j} Gram_il X_lj   (j > i).
+__global__ __launch_bounds__(256) void tf_outer_kernel(const double* __restrict__ Tfp, const double* __restrict__ Gram,
+                                                       double* __restrict__ Tfo, int nb, const int32_t* __restrict__ act) {
+  constexpr int LS = PB + 1;
+  __shared__ double Gs[PB * LS], Xs[PB * LS], Ts[PB * LS], tmp[PB * LS];
+  const int b = blockIdx.x;
+  if (act && !act[b]) return;
+  const int OBs = nb * PB, tid = threadIdx.x;
+  const double* tp = Tfp + size_t(b) * nb * PB * PB;
+  const double* G = Gram + size_t(b) * OBs * OBs;
+  double* X = Tfo + size_t(b) * OBs * OBs;
+  for (int e = tid; e < OBs * OBs; e += 256) {
+    const int r = e / OBs, c = e % OBs;
+    X[e] = (r / PB == c / PB) ? tp[(r / PB) * PB * PB + (r % PB) * PB + (c % PB)] : 0.0;
+  }
+  __syncthreads();
+  for (int dist = 1; dist < nb; ++dist)
+    for (int i = 0; i + dist < nb; ++i) {
+      const int j = i + dist;
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int l = i + 1; l <= j; ++l) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int e = tid + 256 * q, r = e >> 5, cc = e & 31;
+          Gs[r * LS + cc] = G[size_t(i * PB + r) * OBs + l * PB + cc];
+          Xs[r * LS + cc] = X[size_t(l * PB + r) * OBs + j * PB + cc];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int e = tid + 256 * q, r = e >> 5, cc = e & 31;
+#pragma unroll 8
+          for (int m = 0; m < PB; ++m) acc[q] = fma(Gs[r * LS + m], Xs[m * LS + cc], acc[q]);
+        }
+        __syncthreads();
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int e = tid + 256 * q, r = e >> 5, cc = e & 31;
+        tmp[r * LS + cc] = acc[q];
+        Ts[r * LS + cc] = tp[i * PB * PB + e];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int e = tid + 256 * q, r = e >> 5, cc = e & 31;
+        double o = 0.0;
+#pragma unroll 8
+        for (int m = 0; m < PB; ++m) o = fma(Ts[r * LS + m], tmp[m * LS + cc], o);
+        X[size_t(i * PB + r) * OBs + j * PB + cc] = -o;
+      }
+      __syncthreads();
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -488,7 +573,25 @@ __global__ __launch_bounds__(256) void solve_wz_kernel(DenseView v, const StepAr
   forward_vec(v.S + size_t(b) * v.d * v.d, v.d, v.z + size_t(b) * v.d);
 }
 
-// m = m^- - Y wz ; normalised error norm ; output scale of the new state
+// m = m^- - Y wz
+__global__ __launch_bounds__(256) void finish_mean_kernel(DenseView v, const StepArg* __restrict__ args) {
+  const int b = blockIdx.y;
+  const StepArg arg = args[b];
+  if (!arg.active) return;
+  const int d = v.d, D = v.D;
+  double* mdst = v.mean + (size_t(arg.dst) * v.B + b) * D;
+  const double* Y = v.Ft + size_t(b) * D * d;
+  const double* wz = v.z + size_t(b) * d;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int r = blockIdx.x * 4 + wv; r < D; r += 4 * gridDim.x) {
+    double acc = 0.0;
+    for (int a = lane; a < d; a += kWave) acc = fma(Y[size_t(r) * d + a], wz[a], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) mdst[r] -= acc;
+  }
+}
+
+// normalised error norm ; output scale of the new state
 __global__ __launch_bounds__(256) void finish_kernel(DenseView v, const StepArg* __restrict__ args) {
   __shared__ double red[4];
   const int b = blockIdx.x;
@@ -496,17 +599,7 @@ __global__ __launch_bounds__(256) void finish_kernel(DenseView v, const StepArg*
   if (!arg.active) return;
   const int d = v.d, D = v.D;
   const size_t sB = size_t(v.B);
-  double* mdst = v.mean + (size_t(arg.dst) * sB + b) * D;
-  const double* Y = v.Ft + size_t(b) * D * d;
-  const double* wz = v.z + size_t(b) * d;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int r = wv; r < D; r += 4) {
-    double acc = 0.0;
-    for (int a = lane; a < d; a += kWave) acc = fma(Y[size_t(r) * d + a], wz[a], acc);
-    acc = wave_sum(acc);
-    if (lane == 0) mdst[r] -= acc;
-  }
-  __syncthreads();
+  const double* mdst = v.mean + (size_t(arg.dst) * sB + b) * D;
   const double atol = v.atol[b], rtol = v.rtol[b];
   double part = 0.0;
   for (int j = threadIdx.x; j < d; j += 256) {
@@ -535,8 +628,63 @@ static void potrf(hipStream_t s, const DenseView& v) {
 }
 
 template <int DT>
-static void launch_panel(const DenseView& v, int p0, double* Tf, hipStream_t s) {
-  hipLaunchKernelGGL(lq_panel_kernel<DT>, dim3(v.B), dim3(512), 0, s, v, p0, Tf);
+static void launch_panel(const DenseView& v, int p0, double* Tf, int tf_stride, hipStream_t s) {
+  hipLaunchKernelGGL(lq_panel_kernel<DT>, dim3(v.B), dim3(1024), 0, s, v, p0, Tf, tf_stride);
+}
+
+// Blocked row-Householder LQ of the rows_total x 2D stack [T | Mt] in v.R / v.M (rows >= D are updated, never pivoted).
+// Two levels: 32-row panels are applied inside their 128-row outer block only; the outer block's aggregated reflector
+// (Y = 128 scaled rows, 128 x 128 factor) then updates all rows below in one pass: G = T[:, blk] + Mt V^T, W = G Tf,
+// T[:, blk] -= W, Mt -= W V  -- a quarter of the trailing-matrix traffic of panel-by-panel updates.
+static void blocked_lq(const DenseView& v, int rows_total, hipStream_t s) {
+  const int B = v.B, D = v.D;
+  const int OB = D < 128 ? D : 128, nb = OB / PB;
+  const long sDD = long(v.mr_rows) * D * D;
+  const long sG = long(rows_total) * OB;
+  const int tfs = nb * PB * PB;
+  for (int o0 = 0; o0 < D; o0 += OB) {
+    for (int pi = 0; pi < nb; ++pi) {
+      const int p0 = o0 + pi * PB;
+      double* Tf = v.lgTf + size_t(pi) * PB * PB;
+      switch (D / 16) {
+        case 8: launch_panel<8>(v, p0, Tf, tfs, s); break;
+        case 16: launch_panel<16>(v, p0, Tf, tfs, s); break;
+        case 32: launch_panel<32>(v, p0, Tf, tfs, s); break;
+        case 48: launch_panel<48>(v, p0, Tf, tfs, s); break;
+        default: launch_panel<64>(v, p0, Tf, tfs, s); break;
+      }
+      const int j0 = p0 + PB;
+      const int rows = o0 + OB - j0;
+      if (rows <= 0) continue;
+      double* Mb = v.M + size_t(j0) * D;       // trailing rows of Mt (inside the outer block)
+      double* Vp = v.M + size_t(p0) * D;       // scaled reflector rows (32 x D)
+      double* Tb = v.R + size_t(j0) * D + p0;  // trailing rows of T, panel columns
+      Gemm g1{Mb, Vp, Tb, v.lgG, sDD, sDD, sDD, sG, D, D, D, PB, rows, PB, D, 1.0, 1.0, v.act, nullptr};
+      gemm(s, B, true, g1);  // G = T[:, panel] + Mt V^T
+      Gemm g2{v.lgG, Tf, nullptr, v.lgW, sG, long(tfs), 0, sG, PB, PB, 0, PB, rows, PB, PB, 1.0, 0.0, v.act, nullptr};
+      gemm(s, B, false, g2);  // W = G Tf
+      Gemm g3{v.lgG, Tf, Tb, Tb, sG, long(tfs), sDD, sDD, PB, PB, D, D, rows, PB, PB, -1.0, 1.0, v.act, nullptr};
+      gemm(s, B, false, g3);  // T[:, panel] -= G Tf
+      Gemm g4{v.lgW, Vp, Mb, Mb, sG, sDD, sDD, sDD, PB, D, D, D, rows, D, PB, -1.0, 1.0, v.act, nullptr};
+      gemm(s, B, false, g4);  // Mt -= W V
+    }
+    const int j0 = o0 + OB, rows = rows_total - j0;
+    if (rows <= 0) continue;
+    double* Vo = v.M + size_t(o0) * D;        // OB scaled reflector rows
+    double* Mb = v.M + size_t(j0) * D;
+    double* Tb = v.R + size_t(j0) * D + o0;
+    Gemm gg{Vo, Vo, nullptr, v.lgGram, sDD, sDD, 0, long(OB) * OB, D, D, 0, OB, OB, OB, D, 1.0, 0.0, v.act, nullptr};
+    gemm(s, B, true, gg);  // Gram = V V^T
+    hipLaunchKernelGGL(tf_outer_kernel, dim3(B), dim3(256), 0, s, v.lgTf, v.lgGram, v.lgTfo, nb, v.act);
+    Gemm g1{Mb, Vo, Tb, v.lgG, sDD, sDD, sDD, sG, D, D, D, OB, rows, OB, D, 1.0, 1.0, v.act, nullptr};
+    gemm(s, B, true, g1);
+    Gemm g2{v.lgG, v.lgTfo, nullptr, v.lgW, sG, long(OB) * OB, 0, sG, OB, OB, 0, OB, rows, OB, OB, 1.0, 0.0, v.act, nullptr};
+    gemm(s, B, false, g2);
+    Gemm g3{v.lgG, v.lgTfo, Tb, Tb, sG, long(OB) * OB, sDD, sDD, OB, OB, D, D, rows, OB, OB, -1.0, 1.0, v.act, nullptr};
+    gemm(s, B, false, g3);
+    Gemm g4{v.lgW, Vo, Mb, Mb, sG, sDD, sDD, sDD, OB, D, D, D, rows, D, OB, -1.0, 1.0, v.act, nullptr};
+    gemm(s, B, false, g4);
+  }
 }
 
 }  // namespace lg
@@ -567,30 +715,7 @@ void dense_large_launch_step(const DenseView& v, const StepArg* args, const IwpC
   // ---- time update: blocked row-Householder LQ of [T | Mt]
   dense_launch_lq_input(v, args, K, s);
   mark(2);
-  const int rows_total = v.mr_rows * D;  // == D (filter)
-  for (int p0 = 0; p0 < D; p0 += PB) {
-    switch (D / 16) {
-      case 8: launch_panel<8>(v, p0, v.lgTf, s); break;
-      case 16: launch_panel<16>(v, p0, v.lgTf, s); break;
-      case 32: launch_panel<32>(v, p0, v.lgTf, s); break;
-      case 48: launch_panel<48>(v, p0, v.lgTf, s); break;
-      default: launch_panel<64>(v, p0, v.lgTf, s); break;
-    }
-    const int j0 = p0 + PB, rows = rows_total - j0;
-    if (rows <= 0) break;
-    double* Mb = v.M + size_t(j0) * D;         // trailing rows of Mt
-    double* Vp = v.M + size_t(p0) * D;         // scaled reflector rows (32 x D)
-    double* Tb = v.R + size_t(j0) * D + p0;    // trailing rows of T, panel columns
-    const long sG = long(rows_total) * PB;
-    Gemm g1{Mb, Vp, Tb, v.lgG, sDD, sDD, sDD, sG, D, D, D, PB, rows, PB, D, 1.0, 1.0, v.act, nullptr};
-    gemm(s, B, true, g1);  // G = T[:, panel] + Mt V^T
-    Gemm g2{v.lgG, v.lgTf, nullptr, v.lgW, sG, long(PB) * PB, 0, sG, PB, PB, 0, PB, rows, PB, PB, 1.0, 0.0, v.act, nullptr};
-    gemm(s, B, false, g2);  // W = G Tf
-    Gemm g3{v.lgG, v.lgTf, Tb, Tb, sG, long(PB) * PB, sDD, sDD, PB, PB, D, D, rows, PB, PB, -1.0, 1.0, v.act, nullptr};
-    gemm(s, B, false, g3);  // T[:, panel] -= G Tf
-    Gemm g4{v.lgW, Vp, Mb, Mb, sG, sDD, sDD, sDD, PB, D, D, D, rows, D, PB, -1.0, 1.0, v.act, nullptr};
-    gemm(s, B, false, g4);  // Mt -= W V
-  }
+  blocked_lq(v, v.mr_rows * D, s);
   mark(3);
   // ---- measurement update (projector form)
   hipLaunchKernelGGL(scale_t_kernel, dim3(64, B), dim3(256), 0, s, v, args, K);
@@ -621,6 +746,7 @@ void dense_large_launch_step(const DenseView& v, const StepArg* args, const IwpC
     Gemm u{v.Ft, v.X, v.M, v.U, long(D) * d, long(d) * D, sDD, 0, d, D, D, D, D, D, d, -1.0, 1.0, v.act, v.lgOff};
     gemm(s, B, false, u);
   }
+  hipLaunchKernelGGL(finish_mean_kernel, dim3(32, B), dim3(256), 0, s, v, args);
   hipLaunchKernelGGL(finish_kernel, dim3(B), dim3(256), 0, s, v, args);
   mark(4);
 }

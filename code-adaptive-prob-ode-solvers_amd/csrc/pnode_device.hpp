@@ -72,9 +72,11 @@ struct DenseView {
   double* ck_Lam;   // [B][K][D][D]
   // large-D path (pnode_dense_large.hip): panel scratch of the blocked LQ and per-trajectory output offsets
   int force_large;  // 1: take the large-D path whenever it supports the shape (A/B testing at small D)
-  double* lgG;      // [B][mr_rows*D][32]
-  double* lgW;      // [B][mr_rows*D][32]
-  double* lgTf;     // [B][32][32]
+  double* lgG;      // [B][mr_rows*D][128]
+  double* lgW;      // [B][mr_rows*D][128]
+  double* lgTf;     // [B][4][32][32]  panel factors of the current outer block
+  double* lgGram;   // [B][128][128]
+  double* lgTfo;    // [B][128][128]   aggregated factor of the outer block
   long* lgOff;      // [B]
 };
 

@@ -27,7 +27,10 @@ def run(N, nu, B, path, steps=5):
     bt.close()
 
 if __name__ == "__main__":
-    run(32, 3, 256, 0); run(32, 3, 256, 2)
-    run(64, 3, 64, 2)
-    run(128, 3, 64, 2)
-    run(128, 3, 2, 1, steps=1)
+    if len(sys.argv) > 1:
+        N, B, path = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+        run(N, 3, B, path)
+    else:
+        run(32, 3, 256, 0); run(32, 3, 256, 2)
+        run(64, 3, 64, 2)
+        run(128, 3, 64, 2)
