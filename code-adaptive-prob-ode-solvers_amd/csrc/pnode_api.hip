@@ -317,17 +317,29 @@ int pnode_create(const pnode_config* cfg, pnode_batch** out) {
     ALLOC(v.sig_new, B);
     {
       const int DT = int(D) / 16;
-      if (v.ts1 && !v.fixedpoint && d % 32 == 0 && (DT == 8 || DT == 16 || DT == 32 || DT == 48 || DT == 64)) {
+      if (v.ts1 && d % 32 == 0 && D % 128 == 0 && (DT == 8 || DT == 16 || DT == 32 || DT == 48 || DT == 64)) {
         ALLOC(v.lgG, B * v.mr_rows * D * 128);
         ALLOC(v.lgW, B * v.mr_rows * D * 128);
         ALLOC(v.lgTf, B * 4 * 32 * 32);
         ALLOC(v.lgGram, B * 128 * 128);
         ALLOC(v.lgTfo, B * 128 * 128);
         ALLOC(v.lgOff, B);
+        if (v.fixedpoint) {
+          ALLOC(v.lgMaskMerge, B);
+          ALLOC(v.lgOffS, B);
+          ALLOC(v.lgOffD, B);
+          ALLOC(v.lgXi, B * D);
+        }
       }
     }
     v.atol = h->dAtol; v.rtol = h->dRtol; v.prm = nprm ? h->dPrm : nullptr; v.errnorm = h->zErr;
     v.user_f = h->dUserF; v.user_J = h->dUserJ;
+    // A/B testing through the high-level API: PNODE_DENSE_PATH=1 (generic kernels) / 2 (large-D path where supported)
+    if (const char* pth = getenv("PNODE_DENSE_PATH")) {
+      const int e = atoi(pth);
+      if (e == 1) { v.force_generic = 1; v.user_generic = 1; }
+      if (e == 2 && dense_large_supported(v)) v.force_large = 1;
+    }
   }
   h->t_sf.assign(B, 0.0);
   h->t_if.assign(B, 0.0);
@@ -959,7 +971,8 @@ int pnode_last_step_ms(pnode_batch* h, float* ms_out) {
 int pnode_set_generic_path(pnode_batch* h, int32_t enabled) {
   if (!h) return fail(PNODE_EINVAL, "null handle");
   if (enabled == 2 && !dense_large_supported(h->dn)) return fail(PNODE_EINVAL, "the large-D path does not support this shape");
-  h->dn.force_generic = enabled == 1;
+  h->dn.force_generic = enabled == 1 || h->dn.fixedpoint;  // the register-resident MFMA kernels have no extra-row LQ
+  h->dn.user_generic = enabled == 1;
   h->dn.force_large = enabled == 2;
   return PNODE_OK;
 }

@@ -378,7 +378,7 @@ void dense_launch_step(const DenseView& v, const StepArg* args, const IwpConst* 
     return;
   }
   const bool fast = dense_mfma_supported(v) && !v.force_generic;
-  if (dense_large_supported(v) && !v.force_generic && (v.force_large || !fast)) {
+  if (dense_use_large(v)) {
     dense_large_launch_step(v, args, K, s, ev);
     return;
   }

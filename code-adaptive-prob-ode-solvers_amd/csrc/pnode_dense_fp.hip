@@ -274,9 +274,13 @@ __global__ __launch_bounds__(kT) void dfp_smooth_kernel(DenseView v, const int32
 }
 
 static void fp_backward_chain(const DenseView& v, const FpArg* fa, const IwpConst* K, hipStream_t s) {
-  const size_t shm = size_t(v.D) * sizeof(double);
-  hipLaunchKernelGGL(dfp_backward_kernel, dim3(v.B), dim3(kT), shm, s, v, fa, K);
-  dense_launch_lq_generic(v, v.D, s);  // lq([Lam0 | G0 Lam_raw]) -> merged noise factor
+  if (dense_use_large(v)) {
+    dense_large_fp_backward(v, fa, K, s);  // batched GEMM / blocked TRSM + blocked LQ (pnode_dense_large.hip)
+  } else {
+    const size_t shm = size_t(v.D) * sizeof(double);
+    hipLaunchKernelGGL(dfp_backward_kernel, dim3(v.B), dim3(kT), shm, s, v, fa, K);
+    dense_launch_lq_generic(v, v.D, s);  // lq([Lam0 | G0 Lam_raw]) -> merged noise factor
+  }
   hipLaunchKernelGGL(dfp_store_lam_kernel, dim3(v.D < 64 ? v.D : 64, v.B), dim3(kT), 0, s, v, fa);
 }
 
@@ -291,7 +295,10 @@ void dense_fp_launch_interp(const DenseView& v, const InterpArg* iargs, const Fp
   hipLaunchKernelGGL(dfp_set_sigma_kernel, dim3((v.B + 63) / 64), dim3(64), 0, s, v, iargs);
   for (const FpArg* op : {op1, op2}) {
     hipLaunchKernelGGL(dfp_prep_kernel, dim3(rows, v.B), dim3(kT), 0, s, v, op, K);
-    dense_launch_lq_generic(v, 2 * v.D, s);
+    if (dense_use_large(v))
+      dense_large_lq(v, 2 * v.D, s);
+    else
+      dense_launch_lq_generic(v, 2 * v.D, s);
     hipLaunchKernelGGL(dfp_state_kernel, dim3(rows, v.B), dim3(kT), 0, s, v, op, K);
     fp_backward_chain(v, op, K, s);
   }

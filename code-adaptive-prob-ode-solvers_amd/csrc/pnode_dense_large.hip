@@ -36,6 +36,8 @@ struct Gemm {
   double alpha, beta;
   const int32_t* act;  // per-trajectory activity flags (nullptr: all)
   const long* offC;    // optional per-trajectory element offsets of C (replaces b * sC)
+  const long* offA;    // same for A
+  const long* offB;    // same for B
 };
 
 template <bool TB, int WMs, int WNs>
@@ -51,8 +53,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(Gemm g) {
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, gq = lane >> 4;
   const int wm = w / WNs, wn = w % WNs;
-  const double* A = g.A + long(b) * g.sA;
-  const double* Bm = g.B + long(b) * g.sB;
+  const double* A = g.A + (g.offA ? g.offA[b] : long(b) * g.sA);
+  const double* Bm = g.B + (g.offB ? g.offB[b] : long(b) * g.sB);
   const double4_t zero4 = {0.0, 0.0, 0.0, 0.0};
   double4_t acc[2][2] = {{zero4, zero4}, {zero4, zero4}};
   double4_t ra[APASS], rb;
@@ -502,6 +504,7 @@ __global__ __launch_bounds__(256) void begin_a_kernel(DenseView v, const StepArg
       for (int kk = i; kk < n; ++kk) acc += K.a[i][kk] * pinv[kk] * msrc[kk * d + j];
       const double e = p[i] * acc;
       mdst[i * d + j] = e;
+      if (v.fixedpoint) v.mext[size_t(b) * n * d + i * d + j] = e;
       if (i < k) ybuf[i * d + j] = e;
     }
   __syncthreads();
@@ -627,6 +630,133 @@ static void potrf(hipStream_t s, const DenseView& v) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Fixed-point smoother on the large-D path: backward transition of the predict just factorised + merge with the
+// running one (same algebra as dfp_backward_kernel in pnode_dense_fp.hip, as batched GEMM / blocked TRSM).
+// ---------------------------------------------------------------------------------------------
+__global__ void fp_setup_kernel(DenseView v, const FpArg* __restrict__ fa) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= v.B) return;
+  const FpArg a = fa[b];
+  const long DD = long(v.D) * v.D;
+  v.act[b] = a.active ? 1 : 0;
+  v.lgMaskMerge[b] = (a.active && a.merge) ? 1 : 0;
+  v.lgOffS[b] = (long(a.src) * v.B + b) * DD;
+  v.lgOffD[b] = (long(a.dst) * v.B + b) * DD;
+}
+
+// X[:, jb] = C21[:, jb] Lm[jb, jb]^-1 for the 32-column block jb (thread per row; zero pivot -> pseudo-inverse)
+__global__ __launch_bounds__(256) void trsm_right_block_kernel(DenseView v, int jb) {
+  __shared__ double Ld[PB * (PB + 1)];
+  const int b = blockIdx.y;
+  if (!v.act[b]) return;
+  const int D = v.D, tid = threadIdx.x, c0 = jb * PB;
+  double* R = v.R + size_t(b) * 2 * D * D;
+  const double* Lm = R;
+  double* C = R + size_t(D) * D;
+  for (int e = tid; e < PB * PB; e += 256) {
+    const int i = e >> 5, j = e & 31;
+    Ld[i * (PB + 1) + j] = (j <= i) ? Lm[size_t(c0 + i) * D + c0 + j] : 0.0;
+  }
+  __syncthreads();
+  const int row = blockIdx.x * 256 + tid;
+  if (row >= D) return;
+  double* cr = C + size_t(row) * D + c0;
+  double x[PB];
+#pragma unroll
+  for (int j = 0; j < PB; ++j) x[j] = cr[j];
+#pragma unroll
+  for (int j = PB - 1; j >= 0; --j) {
+    double acc = x[j];
+#pragma unroll
+    for (int k = j + 1; k < PB; ++k) acc = fma(-x[k], Ld[k * (PB + 1) + j], acc);
+    const double piv = Ld[j * (PB + 1) + j];
+    x[j] = (piv != 0.0) ? acc / piv : 0.0;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int j = 0; j < PB; ++j) cr[j] = x[j];
+}
+
+// back to plain coordinates: G *= p_r / p_c, Lam *= p_r
+__global__ __launch_bounds__(256) void fp_scale_kernel(DenseView v, const FpArg* __restrict__ fa, const IwpConst* __restrict__ Kc) {
+  const int b = blockIdx.y;
+  const FpArg a = fa[b];
+  if (!a.active) return;
+  const int D = v.D, d = v.d;
+  double p[kMaxN], pinv[kMaxN];
+  precond(v.n, a.dt, *Kc, p, pinv);
+  double* G = v.R + size_t(b) * 2 * D * D + size_t(D) * D;
+  double* Lam = v.M + size_t(b) * 2 * D * D + size_t(D) * D;
+  for (int r = blockIdx.x; r < D; r += gridDim.x) {
+    const double pr = p[r / d];
+    for (int c = threadIdx.x; c < D; c += 256) {
+      G[size_t(r) * D + c] *= pr * pinv[c / d];
+      Lam[size_t(r) * D + c] *= pr;
+    }
+  }
+}
+
+// xi = m_prev - G m^-   (into v.lgXi)
+__global__ __launch_bounds__(256) void fp_xi_kernel(DenseView v, const FpArg* __restrict__ fa) {
+  const int b = blockIdx.y;
+  const FpArg a = fa[b];
+  if (!a.active) return;
+  const int D = v.D;
+  const double* G = v.R + size_t(b) * 2 * D * D + size_t(D) * D;
+  const double* mprev = v.mean + (size_t(a.src) * v.B + b) * D;
+  const double* mext = v.mext + size_t(b) * D;
+  double* xi = v.lgXi + size_t(b) * D;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int r = blockIdx.x * 4 + wv; r < D; r += 4 * gridDim.x) {
+    double acc = 0.0;
+    for (int c = lane; c < D; c += kWave) acc = fma(G[size_t(r) * D + c], mext[c], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) xi[r] = mprev[r] - acc;
+  }
+}
+
+// merge: T := Lam0 ; xi_dst = xi0 + G0 xi.   no merge: G_dst = G, Mt := Lam, T := 0, xi_dst = xi.
+__global__ __launch_bounds__(256) void fp_merge_misc_kernel(DenseView v, const FpArg* __restrict__ fa) {
+  const int b = blockIdx.y;
+  const FpArg a = fa[b];
+  if (!a.active) return;
+  const int D = v.D;
+  const size_t sB = size_t(v.B), DD = size_t(D) * D;
+  double* M = v.M + size_t(b) * 2 * DD;
+  double* R = v.R + size_t(b) * 2 * DD;
+  const double* G = R + DD;
+  const double* Lam = M + DD;
+  const double* xi = v.lgXi + size_t(b) * D;
+  double* xi_dst = v.cxi + (size_t(a.dst) * sB + b) * D;
+  if (a.merge) {
+    const double* Lam0 = v.cLam + (size_t(a.src) * sB + b) * DD;
+    const double* G0 = v.cG + (size_t(a.src) * sB + b) * DD;
+    const double* xi0 = v.cxi + (size_t(a.src) * sB + b) * D;
+    for (int r = blockIdx.x; r < D; r += gridDim.x)
+      for (int c = threadIdx.x; c < D; c += 256) R[size_t(r) * D + c] = Lam0[size_t(r) * D + c];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int r = blockIdx.x * 4 + wv; r < D; r += 4 * gridDim.x) {
+      double acc = 0.0;
+      for (int k = lane; k < D; k += kWave) acc = fma(G0[size_t(r) * D + k], xi[k], acc);
+      acc = wave_sum(acc);
+      if (lane == 0) xi_dst[r] = xi0[r] + acc;
+    }
+  } else {
+    double* G_dst = v.cG + (size_t(a.dst) * sB + b) * DD;
+    for (int r = blockIdx.x; r < D; r += gridDim.x)
+      for (int c = threadIdx.x; c < D; c += 256) {
+        const size_t idx = size_t(r) * D + c;
+        G_dst[idx] = G[idx];
+        M[idx] = Lam[idx];
+        R[idx] = 0.0;
+      }
+    if (blockIdx.x == 0)
+      for (int r = threadIdx.x; r < D; r += 256) xi_dst[r] = xi[r];
+  }
+}
+
 template <int DT>
 static void launch_panel(const DenseView& v, int p0, double* Tf, int tf_stride, hipStream_t s) {
   hipLaunchKernelGGL(lq_panel_kernel<DT>, dim3(v.B), dim3(1024), 0, s, v, p0, Tf, tf_stride);
@@ -689,10 +819,48 @@ static void blocked_lq(const DenseView& v, int rows_total, hipStream_t s) {
 
 }  // namespace lg
 
+void dense_large_lq(const DenseView& v, int rows_total, hipStream_t s) { lg::blocked_lq(v, rows_total, s); }
+
+// After the 2D-row LQ of a predict: G_p = C21_p (L^-_p)^-1 (blocked right triangular solve), plain coordinates,
+// xi, merge with the running transition, and the LQ of the merged noise stack [Lam0 | G0 Lam] (rows 0..D-1 of R / M).
+void dense_large_fp_backward(const DenseView& v, const FpArg* fa, const IwpConst* K, hipStream_t s) {
+  using namespace lg;
+  const int B = v.B, D = v.D;
+  const long DD = long(D) * D, sDD = 2 * DD;
+  hipLaunchKernelGGL(fp_setup_kernel, dim3((B + 63) / 64), dim3(64), 0, s, v, fa);
+  double* C21 = v.R + DD;  // rows D..2D-1 of R
+  for (int jb = D / PB - 1; jb >= 0; --jb) {
+    hipLaunchKernelGGL(trsm_right_block_kernel, dim3((D + 255) / 256, B), dim3(256), 0, s, v, jb);
+    if (jb > 0) {
+      Gemm g{C21 + jb * PB, v.R + size_t(jb) * PB * D, C21, C21, sDD, sDD, sDD, sDD, D, D, D, D, D, jb * PB, PB, -1.0, 1.0, v.act,
+             nullptr};
+      gemm(s, B, false, g);  // C21[:, 0:jb*32] -= X[:, jb] Lm[jb, 0:jb*32]
+    }
+  }
+  hipLaunchKernelGGL(fp_scale_kernel, dim3(64, B), dim3(256), 0, s, v, fa, K);
+  hipLaunchKernelGGL(fp_xi_kernel, dim3(32, B), dim3(256), 0, s, v, fa);
+  {
+    Gemm gd{v.cG, C21, nullptr, v.cG, 0, sDD, 0, 0, D, D, 0, D, D, D, D, 1.0, 0.0, v.lgMaskMerge, v.lgOffD, v.lgOffS, nullptr};
+    gemm(s, B, false, gd);  // G_dst = G0 G
+    Gemm gl{v.cG, v.M + DD, nullptr, v.M, 0, sDD, 0, sDD, D, D, 0, D, D, D, D, 1.0, 0.0, v.lgMaskMerge, nullptr, v.lgOffS, nullptr};
+    gemm(s, B, false, gl);  // Mt := G0 Lam
+  }
+  hipLaunchKernelGGL(fp_merge_misc_kernel, dim3(64, B), dim3(256), 0, s, v, fa);
+  blocked_lq(v, D, s);
+}
+
 bool dense_large_supported(const DenseView& v) {
   const int DT = v.D / 16;
-  return v.ts1 && !v.fixedpoint && v.d % 32 == 0 && v.D % 32 == 0 && (DT == 8 || DT == 16 || DT == 32 || DT == 48 || DT == 64) &&
-         v.lgG != nullptr;
+  return v.ts1 && v.d % 32 == 0 && v.D % 128 == 0 && (DT == 8 || DT == 16 || DT == 32 || DT == 48 || DT == 64) && v.lgG != nullptr;
+}
+
+// Filter: D beyond the register-resident MFMA path. Fixed-point smoother: D >= 512 (below that the generic kernels are
+// the reference implementation of the extra-row LQ). pnode_set_generic_path(h, 2) forces it, (h, 1) forbids it.
+bool dense_use_large(const DenseView& v) {
+  if (!dense_large_supported(v)) return false;
+  if (v.force_large) return true;
+  if (v.user_generic) return false;
+  return v.fixedpoint ? v.D >= 512 : !dense_mfma_supported(v);
 }
 
 void dense_large_launch_step(const DenseView& v, const StepArg* args, const IwpConst* K, hipStream_t s, const PhaseEvents* ev) {

@@ -78,6 +78,11 @@ struct DenseView {
   double* lgGram;   // [B][128][128]
   double* lgTfo;    // [B][128][128]   aggregated factor of the outer block
   long* lgOff;      // [B]
+  int user_generic;      // pnode_set_generic_path(h, 1): the caller asked for the generic kernels
+  int32_t* lgMaskMerge;  // [B] fixed-point: trajectories whose running transition is merged in this operation
+  long* lgOffS;          // [B] element offsets of the source / destination slots of the running operation
+  long* lgOffD;          // [B]
+  double* lgXi;          // [B][D]
 };
 
 // Optional per-phase timing of one dense step: events[0..4] bracket begin | lq_input | lq | correct.
@@ -100,6 +105,9 @@ void dense_launch_lq_generic(const DenseView& v, int rows_total, hipStream_t s);
 void dense_launch_lq_input(const DenseView& v, const StepArg* args, const IwpConst* K, hipStream_t s);
 // large-D path (pnode_dense_large.hip): batched MFMA GEMMs + blocked LQ / Cholesky / triangular solve through HBM
 bool dense_large_supported(const DenseView& v);
+bool dense_use_large(const DenseView& v);  // the large-D path is the one that runs for this handle
+void dense_large_lq(const DenseView& v, int rows_total, hipStream_t s);
+void dense_large_fp_backward(const DenseView& v, const FpArg* fa, const IwpConst* K, hipStream_t s);
 void dense_large_launch_step(const DenseView& v, const StepArg* args, const IwpConst* K, hipStream_t s, const PhaseEvents* ev);
 // small-D fused path (pnode_dense_small.hip): one wavefront per trajectory, one kernel per attempt
 bool dense_small_supported(const DenseView& v);

@@ -136,3 +136,26 @@ def test_brusselator_n128_three_quarters_of_a_million_decisions(hip_lib, golden)
     i = list(g["N"]).index(Nn)
     assert int(np.max(sol.num_steps)) == int(g["num_steps_checkpoint"][i]) == 190024
     assert np.max(np.abs(sol.u - g["ys_N128"])) < 1e-9
+
+
+def test_config5_size_dense_smoother_on_the_large_path(hip_lib):
+    """BASELINE config 5 at full state size: Brusselator N = 128 (d = 256), nu = 3, dense EKF1 (D = 1024) with
+    fixed-memory checkpoint smoothing. A short adaptive solve with two checkpoints against the oracle: identical
+    accept/reject decisions, one-step-smoothed checkpoints and fully smoothed means. Batch of 2 (config 5 runs 64 per
+    GPU; the kernels are batch-strided, so the extra trajectories only add runtime)."""
+    Nl, nu, tol = 128, 3, 1e-3
+    vf = V.brusselator(Nl)
+    impl.select("dense", ode_shape=(2 * Nl,))
+    solver = ivpsolvers.solver_dynamic(ivpsolvers.strategy_fixedpoint(ivpsolvers.prior_ibm(nu), ivpsolvers.correction_ts1()))
+    y0 = np.stack([brusselator_y0(Nl, 0.0), brusselator_y0(Nl, 0.8)])
+    tcs = tcoeffs(vf, [y0], nu)
+    init = solver.initial_condition(tcs, 1.0)
+    save_at = np.array([0.0, 0.004, 0.008])
+    sol = ivpsolve.solve_adaptive_save_at(vf, init, save_at=save_at, dt0=0.001, adaptive_solver=ivpsolve.adaptive(solver, atol=tol, rtol=tol))
+    cfg = po.SolverConfig(nu=nu, model="dense", correction="ts1", strategy="fixedpoint", calibration="dynamic")
+    for b in range(2):
+        osol = po.solve_adaptive_save_at(cfg, po.AdaptiveConfig(tol, tol), oracle_problem(vf),
+                                         po.initial_state(cfg, [c[b] for c in tcs], 0.0), save_at, 0.001)
+        assert np.array_equal(sol.num_steps[b], osol.num_steps), b
+        sm = po.markov_marginals_reverse(cfg, osol)
+        assert np.max(np.abs(sol.u[b] - sm[:, 0])) / np.max(np.abs(sm[:, 0])) < 1e-8, b
