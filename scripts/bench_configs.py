@@ -53,7 +53,23 @@ def run(name, vf, u0s, t0, t1, *, model, corr, strategy, nu, atol, rtol, dt0, nu
     print(json.dumps(out), flush=True)
 
 
+def config5(B=64, t1=2.0, tol=1e-4):
+    """C5: Brusselator N=128 (d=256), nu=3, dense EKF1 (D=1024), fixed-memory checkpoint smoothing; 64 trajectories per GPU
+    (512 over 8). Phase-shifted initial profiles as in bench.problem_batch."""
+    N = 128
+    vf, u0, (t0, _), _ = ivps.brusselator(N)
+    x = np.linspace(0.0, 1.0, N)
+    ph = 2.0 * np.pi * np.arange(B) / B
+    y0 = np.concatenate([1.0 + np.sin(2 * np.pi * x[None, :] + ph[:, None]), 3.0 * np.ones((B, N))], axis=1)
+    for strategy in ("filter", "fixedpoint"):
+        run(f"C5 brusselator N=128 dense EKF1 nu=3 {strategy}", vf, [y0], t0, t1, model="dense", corr="ts1", strategy=strategy,
+            nu=3, atol=tol, rtol=tol, dt0=0.01, num_save=5)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "c5":
+        config5()
+        return
     from scipy.integrate import solve_ivp
 
     # C1: Van der Pol mu=1, d=2, nu=3, EKF0 isotropic, single trajectory
