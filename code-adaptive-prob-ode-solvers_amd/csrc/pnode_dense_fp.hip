@@ -183,8 +183,9 @@ __global__ void dfp_set_sigma_kernel(DenseView v, const InterpArg* __restrict__ 
 
 // Checkpoint bookkeeping after the two predicts of an interpolation (tmpA = slot 3: state at t with the merged
 // transition; tmpB = slot 4: transition t1 -> t), or for a checkpoint that coincides with STEP_FROM.
+// Grid (G, B): the D x D copies are spread over the G workgroups of a trajectory; block 0 also moves the vectors.
 __global__ __launch_bounds__(kT) void dfp_interp_finish_kernel(DenseView v, const InterpArg* __restrict__ ia) {
-  const int b = blockIdx.x;
+  const int b = blockIdx.y;
   const InterpArg a = ia[b];
   if (a.ckpt < 0) return;
   const int D = v.D;
@@ -199,13 +200,15 @@ __global__ __launch_bounds__(kT) void dfp_interp_finish_kernel(DenseView v, cons
   auto slotX = [&](int s) { return v.cxi + (size_t(s) * sB + b) * D; };
   auto slotM = [&](int s) { return v.mean + (size_t(s) * sB + b) * D; };
   auto slotU = [&](int s) { return v.U + (size_t(s) * sB + b) * DD; };
+  const size_t gtid = size_t(blockIdx.x) * kT + threadIdx.x, gstride = size_t(gridDim.x) * kT;
+  const int lane = threadIdx.x & 63, gw = blockIdx.x * (kT / 64) + (threadIdx.x >> 6), nw = gridDim.x * (kT / 64);
   if (a.at_step) {
-    for (int r = threadIdx.x; r < D; r += kT) {
+    for (size_t r = gtid; r < size_t(D); r += gstride) {
       cm[r] = slotM(a.s1)[r];
       cx[r] = slotX(a.s1)[r];
       slotX(a.s1)[r] = 0.0;
     }
-    for (size_t idx = threadIdx.x; idx < DD; idx += kT) {
+    for (size_t idx = gtid; idx < DD; idx += gstride) {
       cG[idx] = slotG(a.s1)[idx];
       cL[idx] = slotL(a.s1)[idx];
       slotG(a.s1)[idx] = (idx / D == idx % D) ? 1.0 : 0.0;
@@ -215,19 +218,19 @@ __global__ __launch_bounds__(kT) void dfp_interp_finish_kernel(DenseView v, cons
     const int tA = 3, tB = 4;
     const double* G1 = slotG(tB);
     const double* m1 = slotM(a.s1);
-    for (int r = threadIdx.x; r < D; r += kT) {
-      double acc = slotX(tB)[r];
-      for (int c = 0; c < D; ++c) acc += G1[size_t(r) * D + c] * m1[c];
-      cm[r] = acc;                       // solution at the checkpoint: G1 m(t1) + xi1
-      cx[r] = slotX(tA)[r];
+    for (int r = gw; r < D; r += nw) {  // solution at the checkpoint: G1 m(t1) + xi1 (one wavefront per row)
+      double acc = 0.0;
+      for (int c = lane; c < D; c += 64) acc = fma(G1[size_t(r) * D + c], m1[c], acc);
+      acc = wave_sum(acc);
+      if (lane == 0) cm[r] = acc + slotX(tB)[r];
     }
-    __syncthreads();
-    for (int r = threadIdx.x; r < D; r += kT) {
+    for (size_t r = gtid; r < size_t(D); r += gstride) {
+      cx[r] = slotX(tA)[r];
       slotX(a.s1)[r] = slotX(tB)[r];     // STEP_FROM remembers how to get back to t
       slotM(a.s0)[r] = slotM(tA)[r];     // INTERP_FROM <- filtering state at t ...
       slotX(a.s0)[r] = 0.0;              //   ... with an identity transition
     }
-    for (size_t idx = threadIdx.x; idx < DD; idx += kT) {
+    for (size_t idx = gtid; idx < DD; idx += gstride) {
       cG[idx] = slotG(tA)[idx];
       cL[idx] = slotL(tA)[idx];
       slotG(a.s1)[idx] = slotG(tB)[idx];
@@ -236,12 +239,12 @@ __global__ __launch_bounds__(kT) void dfp_interp_finish_kernel(DenseView v, cons
       slotG(a.s0)[idx] = (idx / D == idx % D) ? 1.0 : 0.0;
       slotL(a.s0)[idx] = 0.0;
     }
-    if (threadIdx.x == 0) v.sigma[size_t(a.s0) * sB + b] = v.sig_new[b];
+    if (gtid == 0) v.sigma[size_t(a.s0) * sB + b] = v.sig_new[b];
   }
-  if (threadIdx.x == 0) v.ck_steps[ck] = a.steps;
+  if (gtid == 0) v.ck_steps[ck] = a.steps;
 }
 
-// Backward pass over the stored checkpoint transitions: out [B][K+1][D].
+// Backward pass over the stored checkpoint transitions: out [B][K+1][D]. One wavefront per row of G.
 __global__ __launch_bounds__(kT) void dfp_smooth_kernel(DenseView v, const int32_t* __restrict__ num_filled, double* __restrict__ out) {
   extern __shared__ double mbuf[];  // [2][D]
   const int b = blockIdx.x;
@@ -257,14 +260,18 @@ __global__ __launch_bounds__(kT) void dfp_smooth_kernel(DenseView v, const int32
     ob[size_t(nf) * D + r] = last[r];
   }
   __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   for (int c = nf - 1; c >= 0; --c) {
     const double* G = v.ck_G + (size_t(b) * v.K + c) * D * D;
     const double* xi = v.ck_xi + (size_t(b) * v.K + c) * D;
-    for (int r = threadIdx.x; r < D; r += kT) {
-      double acc = xi[r];
-      for (int k = 0; k < D; ++k) acc += G[size_t(r) * D + k] * cur[k];
-      nxt[r] = acc;
-      ob[size_t(c) * D + r] = acc;
+    for (int r = wv; r < D; r += kT / 64) {
+      double acc = 0.0;
+      for (int k = lane; k < D; k += 64) acc = fma(G[size_t(r) * D + k], cur[k], acc);
+      acc = wave_sum(acc);
+      if (lane == 0) {
+        nxt[r] = acc + xi[r];
+        ob[size_t(c) * D + r] = acc + xi[r];
+      }
     }
     __syncthreads();
     double* t = cur;
@@ -302,7 +309,7 @@ void dense_fp_launch_interp(const DenseView& v, const InterpArg* iargs, const Fp
     hipLaunchKernelGGL(dfp_state_kernel, dim3(rows, v.B), dim3(kT), 0, s, v, op, K);
     fp_backward_chain(v, op, K, s);
   }
-  hipLaunchKernelGGL(dfp_interp_finish_kernel, dim3(v.B), dim3(kT), 0, s, v, iargs);
+  hipLaunchKernelGGL(dfp_interp_finish_kernel, dim3(v.D >= 256 ? 32 : 4, v.B), dim3(kT), 0, s, v, iargs);
 }
 
 void dense_fp_launch_smooth(const DenseView& v, const int32_t* num_filled, double* out, hipStream_t s) {
