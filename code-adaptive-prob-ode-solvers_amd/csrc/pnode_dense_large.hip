@@ -854,13 +854,14 @@ bool dense_large_supported(const DenseView& v) {
   return v.ts1 && v.d % 32 == 0 && v.D % 128 == 0 && (DT == 8 || DT == 16 || DT == 32 || DT == 48 || DT == 64) && v.lgG != nullptr;
 }
 
-// Filter: D beyond the register-resident MFMA path. Fixed-point smoother: D >= 512 (below that the generic kernels are
-// the reference implementation of the extra-row LQ). pnode_set_generic_path(h, 2) forces it, (h, 1) forbids it.
+// Filter: D beyond the register-resident MFMA path. Fixed-point smoother: every supported shape (the register-resident
+// kernels have no extra-row LQ; the alternative is the generic kernels). pnode_set_generic_path(h, 2) forces the path,
+// (h, 1) forbids it.
 bool dense_use_large(const DenseView& v) {
   if (!dense_large_supported(v)) return false;
   if (v.force_large) return true;
   if (v.user_generic) return false;
-  return v.fixedpoint ? v.D >= 512 : !dense_mfma_supported(v);
+  return v.fixedpoint ? true : !dense_mfma_supported(v);
 }
 
 void dense_large_launch_step(const DenseView& v, const StepArg* args, const IwpConst* K, hipStream_t s, const PhaseEvents* ev) {

@@ -535,15 +535,16 @@ def test_small_dense_fused_kernel_and_device_controller(hip_lib):
         assert relmax(host.u[0], osol.u) < 1e-8 and np.max(np.abs(dev.u - host.u)) < 1e-11, vf2.d
 
 
-@pytest.mark.parametrize("case", ["brusselator4", "rigid", "vdp2", "brusselator16_large"])
+@pytest.mark.parametrize("case", ["brusselator4", "rigid", "vdp2", "brusselator16_large", "brusselator16_generic"])
 def test_dense_fixedpoint_smoother_vs_oracle(hip_lib, case, monkeypatch):
     """strategy_fixedpoint with the dense model (BASELINE config 5's smoother, at test size): adaptive solve with
     checkpoints; accepted steps, one-step-smoothed checkpoint values and fully smoothed means against the oracle.
     "brusselator16_large" (d = 32, D = 128) forces the large-D kernels config 5 runs on at D = 1024."""
     if case == "brusselator4":
         vf, nu, corr, u0s, tol, save_at, dt0 = V.brusselator(4), 3, "ts1", [brusselator_y0(4)], 1e-5, np.linspace(0, 1.0, 6), 0.01
-    elif case == "brusselator16_large":
-        monkeypatch.setenv("PNODE_DENSE_PATH", "2")
+    elif case in ("brusselator16_large", "brusselator16_generic"):
+        # d = 32, D = 128: the large-D kernels are the default for the smoother; "generic" pins the reference kernels
+        monkeypatch.setenv("PNODE_DENSE_PATH", "2" if case.endswith("large") else "1")
         vf, nu, corr, u0s, tol, save_at, dt0 = V.brusselator(16), 3, "ts1", [brusselator_y0(16)], 1e-4, np.linspace(0, 0.5, 4), 0.01
     elif case == "rigid":
         vf, nu, corr, u0s, tol, save_at, dt0 = V.rigid_body(), 2, "ts1", [np.array([1.0, 0.0, 0.9])], 1e-4, np.linspace(0, 4.0, 5), 0.1
