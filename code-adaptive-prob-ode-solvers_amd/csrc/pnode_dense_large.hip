@@ -40,7 +40,10 @@ struct Gemm {
   const long* offB;    // same for B
 };
 
-template <bool TB, int WMs, int WNs>
+// PD = register prefetch depth in k-tiles: the skinny shapes (N <= 32: a handful of workgroups per trajectory, K up to D)
+// are bound by the global-load latency of their k-loop, so they keep four tiles in flight; the square shapes hide it
+// with occupancy and keep one.
+template <bool TB, int WMs, int WNs, int PD>
 __global__ __launch_bounds__(256) void gemm_kernel(Gemm g) {
   static_assert(WMs * WNs == 4, "four waves per workgroup");
   constexpr int BM = 32 * WMs, BN = 32 * WNs, KS = 16, LDAS = KS + 1;
@@ -57,41 +60,55 @@ __global__ __launch_bounds__(256) void gemm_kernel(Gemm g) {
   const double* Bm = g.B + (g.offB ? g.offB[b] : long(b) * g.sB);
   const double4_t zero4 = {0.0, 0.0, 0.0, 0.0};
   double4_t acc[2][2] = {{zero4, zero4}, {zero4, zero4}};
-  double4_t ra[APASS], rb;
+  double4_t ra[PD][APASS], rb[PD];
   const int lrow = tid >> 2, lc4 = (tid & 3) * 4;               // A tile / transposed B tile: 64 rows x 16 per pass
   const int nkr = tid / (BN / 4), nc4 = (tid % (BN / 4)) * 4;   // B tile (not transposed): 16 rows x BN
-  auto fetch = [&](int kk) {
+  // Loads are unconditional (clamped addresses, values masked afterwards) so that the compiler can count the loads in
+  // flight exactly (s_waitcnt vmcnt(n) instead of vmcnt(0)) and the prefetch depth is real.
+  auto fetch = [&](int kk, double4_t (&qa)[APASS], double4_t& qb) {
 #pragma unroll
     for (int p = 0; p < APASS; ++p) {
       const int gr = m0 + p * 64 + lrow;
-      ra[p] = (gr < g.M) ? *reinterpret_cast<const double4_t*>(A + long(gr) * g.lda + kk + lc4) : zero4;
+      const int grc = gr < g.M ? gr : g.M - 1;
+      const double4_t t = *reinterpret_cast<const double4_t*>(A + long(grc) * g.lda + kk + lc4);
+      qa[p] = (gr < g.M) ? t : zero4;
     }
     if (TB) {
       const int gn = n0 + lrow;
-      rb = (lrow < BN && gn < g.N) ? *reinterpret_cast<const double4_t*>(Bm + long(gn) * g.ldb + kk + lc4) : zero4;
+      const int gnc = gn < g.N ? gn : g.N - 1;
+      const double4_t t = *reinterpret_cast<const double4_t*>(Bm + long(gnc) * g.ldb + kk + lc4);
+      qb = (lrow < BN && gn < g.N) ? t : zero4;
     } else {
-      rb = (nkr < KS && n0 + nc4 < g.N) ? *reinterpret_cast<const double4_t*>(Bm + long(kk + nkr) * g.ldb + n0 + nc4) : zero4;
+      const int kr = nkr < KS ? nkr : KS - 1;
+      const int cc = n0 + nc4 < g.N ? n0 + nc4 : g.N - 4;
+      const double4_t t = *reinterpret_cast<const double4_t*>(Bm + long(kk + kr) * g.ldb + cc);
+      qb = (nkr < KS && n0 + nc4 < g.N) ? t : zero4;
     }
   };
-  auto stash = [&]() {
+  auto stash = [&](const double4_t (&qa)[APASS], const double4_t& qb) {
 #pragma unroll
     for (int p = 0; p < APASS; ++p)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) As[(p * 64 + lrow) * LDAS + lc4 + q] = ra[p][q];
+      for (int q = 0; q < 4; ++q) As[(p * 64 + lrow) * LDAS + lc4 + q] = qa[p][q];
     if (TB) {
       if (lrow < BN)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) Bs[lrow * LDBS + lc4 + q] = rb[q];
+        for (int q = 0; q < 4; ++q) Bs[lrow * LDBS + lc4 + q] = qb[q];
     } else if (nkr < KS) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) Bs[nkr * LDBS + nc4 + q] = rb[q];
+      for (int q = 0; q < 4; ++q) Bs[nkr * LDBS + nc4 + q] = qb[q];
     }
   };
-  fetch(0);
-  for (int kk = 0; kk < g.K; kk += KS) {
-    stash();
+  const int klast = g.K - KS;
+#pragma unroll
+  for (int u = 0; u < PD; ++u) fetch(u * KS < klast ? u * KS : klast, ra[u], rb[u]);
+  for (int kk0 = 0; kk0 < g.K; kk0 += PD * KS) {
+#pragma unroll
+   for (int u = 0; u < PD; ++u) {
+    const int kk = kk0 + u * KS;  // (the launcher guarantees K % (PD * KS) == 0)
+    stash(ra[u], rb[u]);
     __syncthreads();
-    if (kk + KS < g.K) fetch(kk + KS);
+    fetch(kk + PD * KS < klast ? kk + PD * KS : klast, ra[u], rb[u]);  // (past the end: a harmless re-read of the last tile)
 #pragma unroll
     for (int k4 = 0; k4 < 4; ++k4) {
       double a[2], bb[2];
@@ -106,6 +123,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(Gemm g) {
         for (int tn = 0; tn < 2; ++tn) acc[tm][tn] = LG_MFMA(a[tm], bb[tn], acc[tm][tn]);
     }
     __syncthreads();
+   }
   }
   const double* C0 = g.C0 ? g.C0 + long(b) * g.sC0 : nullptr;
   double* C = g.C + (g.offC ? g.offC[b] : long(b) * g.sC);
@@ -128,16 +146,18 @@ static void gemm(hipStream_t s, int batch, bool transB, const Gemm& g) {
   if (g.M <= 0 || g.N <= 0 || batch <= 0) return;
   if (g.N <= 32) {
     dim3 grid((g.N + 31) / 32, (g.M + 127) / 128, batch);
-    if (transB)
-      hipLaunchKernelGGL((gemm_kernel<true, 4, 1>), grid, dim3(256), 0, s, g);
+    if (transB && g.K % 64 == 0)
+      hipLaunchKernelGGL((gemm_kernel<true, 4, 1, 4>), grid, dim3(256), 0, s, g);
+    else if (transB)
+      hipLaunchKernelGGL((gemm_kernel<true, 4, 1, 1>), grid, dim3(256), 0, s, g);
     else
-      hipLaunchKernelGGL((gemm_kernel<false, 4, 1>), grid, dim3(256), 0, s, g);
+      hipLaunchKernelGGL((gemm_kernel<false, 4, 1, 1>), grid, dim3(256), 0, s, g);
   } else {
     dim3 grid((g.N + 63) / 64, (g.M + 63) / 64, batch);
     if (transB)
-      hipLaunchKernelGGL((gemm_kernel<true, 2, 2>), grid, dim3(256), 0, s, g);
+      hipLaunchKernelGGL((gemm_kernel<true, 2, 2, 1>), grid, dim3(256), 0, s, g);
     else
-      hipLaunchKernelGGL((gemm_kernel<false, 2, 2>), grid, dim3(256), 0, s, g);
+      hipLaunchKernelGGL((gemm_kernel<false, 2, 2, 1>), grid, dim3(256), 0, s, g);
   }
 }
 

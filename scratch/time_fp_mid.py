@@ -7,10 +7,11 @@ import numpy as np
 from probdiffeq_hip import _backend, vector_fields as V
 from helpers import tcoeffs, brusselator_y0
 N, B, path = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+strategy = sys.argv[4] if len(sys.argv) > 4 else "fixedpoint"
 vf = V.brusselator(N)
 y0 = np.stack([brusselator_y0(N, 0.1 * b) for b in range(B)])
 tc = np.stack(tcoeffs(vf, [y0], 3), axis=1)
-bt = _backend.Batch(batch=B, d=vf.d, nu=3, ode_order=1, model="dense", correction="ts1", strategy="fixedpoint",
+bt = _backend.Batch(batch=B, d=vf.d, nu=3, ode_order=1, model="dense", correction="ts1", strategy=strategy,
                     calibration="dynamic", vf_id=vf.vf_id, vf_params=vf.param_array(), num_checkpoints=2)
 bt.set_generic_path(path)
 bt.set_initial(tc, np.zeros(B), np.ones(B)); bt.set_tolerances(1e-6, 1e-6)
@@ -19,4 +20,4 @@ bt.attempt_step(np.full(B, 0.005), one, err); bt.commit(one)
 t0 = time.perf_counter()
 for _ in range(3):
     bt.attempt_step(np.full(B, 0.005), one, err); bt.commit(one)
-print(f"N={N} D={8*N} B={B} path={path}: {(time.perf_counter()-t0)/3*1e3:.2f} ms/step err0={err[0]:.6e}", flush=True)
+print(f"N={N} D={8*N} B={B} path={path} {strategy} graph={not os.environ.get('PNODE_NO_GRAPH')}: {(time.perf_counter()-t0)/3*1e3:.2f} ms/step err0={err[0]:.6e}", flush=True)
