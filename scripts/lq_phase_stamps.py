@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""In-kernel s_memtime stamps of the register-resident LQ kernel (PNODE_ABLATE=128): per-wavefront cycle sums of the
+load | factor A | B update | factor B | T write | trailing strips | end barrier phases."""
 import sys, os, ctypes as C
 sys.path[:0]=['.','code-adaptive-prob-ode-solvers_amd','tests','oracle']
 os.environ['PNODE_ABLATE']=os.environ.get('PNODE_ABLATE','128')

@@ -1,3 +1,5 @@
+#!/usr/bin/env python3
+"""Per-kernel, per-grid-size totals from a rocprofv3 --kernel-trace CSV directory: parse_kernel_trace.py OUT [rows]."""
 import csv, sys, glob, collections
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 agg = collections.defaultdict(lambda: [0, 0.0])
