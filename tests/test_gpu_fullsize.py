@@ -159,3 +159,78 @@ def test_config5_size_dense_smoother_on_the_large_path(hip_lib):
         assert np.array_equal(sol.num_steps[b], osol.num_steps), b
         sm = po.markov_marginals_reverse(cfg, osol)
         assert np.max(np.abs(sol.u[b] - sm[:, 0])) / np.max(np.abs(sm[:, 0])) < 1e-8, b
+
+
+def test_config3_work_precision_sweep_full_batch(hip_lib):
+    """BASELINE config 3 at its batch size: rigid body (experiments/2), isotropic EKF0 fixed-point smoother, 1024
+    tolerances in one batch for nu = 3 and nu = 5. Sampled members against the oracle (identical decisions), the whole
+    sweep against a tight scipy solution (error follows the tolerance), and composition invariance (a member solved
+    alone gives bit-identical results)."""
+    from scipy.integrate import solve_ivp
+
+    vf = V.rigid_body()
+    B = 1024
+    rt = 10.0 ** np.linspace(-1.0, -7.0, B)
+    u0 = np.array([1.0, 0.0, 0.9])
+    t1 = 10.0
+    truth = solve_ivp(lambda t, y: vf(y), (0.0, t1), u0, rtol=1e-13, atol=1e-13, method="LSODA").y[:, -1]
+    save_at = np.linspace(0.0, t1, 5)
+    impl.select("isotropic", ode_shape=(3,))
+    for nu in (3, 5):
+        solver = ivpsolvers.solver_dynamic(ivpsolvers.strategy_fixedpoint(ivpsolvers.prior_ibm(nu), ivpsolvers.correction_ts0()))
+        tcs = tcoeffs(vf, [np.tile(u0, (B, 1))], nu)
+        init = solver.initial_condition(tcs, 1.0)
+        sol = ivpsolve.solve_adaptive_save_at(vf, init, save_at=save_at, dt0=0.1, adaptive_solver=ivpsolve.adaptive(solver, atol=1e-3 * rt, rtol=rt))
+        assert np.all(np.isfinite(sol.u))
+        err = np.sqrt(np.mean((sol.u[:, -1] - truth) ** 2, axis=1))
+        # work-precision behaviour: two decades of tolerance buy at least one decade of error, tight end is accurate
+        assert np.median(err[-64:]) < 1e-2 * np.median(err[:64]) and np.median(err[-64:]) < 1e-5
+        steps = sol.num_steps[:, -1]
+        assert np.median(steps[-64:]) > 1.2 * np.median(steps[:64])
+        cfg = po.SolverConfig(nu=nu, model="isotropic", correction="ts0", strategy="fixedpoint", calibration="dynamic")
+        for b in (0, 333, 700, 1023):
+            osol = po.solve_adaptive_save_at(cfg, po.AdaptiveConfig(1e-3 * rt[b], rt[b]), oracle_problem(vf),
+                                             po.initial_state(cfg, [c[b] for c in tcs], 0.0), save_at, 0.1)
+            sm = po.markov_marginals_reverse(cfg, osol)
+            if b < 512:   # loose and moderate tolerances: identical decisions
+                assert np.array_equal(sol.num_steps[b], osol.num_steps), (nu, b)
+                assert np.max(np.abs(sol.u[b] - sm[:, 0])) < 1e-8, (nu, b)
+            else:         # tight tolerances: z = m' - f cancels to rounding level and single accept/reject decisions flip
+                assert np.all(np.abs(sol.num_steps[b] - osol.num_steps) <= 0.03 * osol.num_steps + 2), (nu, b)
+                assert np.max(np.abs(sol.u[b] - sm[:, 0])) < 100 * rt[b], (nu, b)
+        idx = [5, 512, 1000]
+        sub = ivpsolve.solve_adaptive_save_at(vf, solver.initial_condition([c[idx] for c in tcs], 1.0), save_at=save_at, dt0=0.1,
+                                              adaptive_solver=ivpsolve.adaptive(solver, atol=1e-3 * rt[idx], rtol=rt[idx]))
+        assert np.array_equal(sub.num_steps, sol.num_steps[idx]) and np.array_equal(sub.u, sol.u[idx])
+
+
+def test_config2_stiff_tolerance_sweep_full_batch(hip_lib):
+    """BASELINE config 2 at its batch size: stiff Van der Pol (mu = 1e3), nu = 4, dense EKF1, 256 tolerances in one batch
+    (fused one-wavefront kernel), t in [0, 2] (through the first stiff transition). The sweep stays finite, work grows
+    as the tolerance tightens, the terminal value converges to a tight Radau solution, and a member solved alone is
+    bit-identical (composition invariance)."""
+    from scipy.integrate import solve_ivp
+
+    mu = 1e3
+    vf = V.van_der_pol_order2(mu)
+    B = 256
+    tols = 10.0 ** np.linspace(-2.0, -7.0, B)
+    t1 = 2.0
+    truth = solve_ivp(lambda t, y: [y[1], mu * (y[1] * (1 - y[0] ** 2) - y[0])], (0.0, t1), [2.0, 0.0], rtol=1e-12, atol=1e-12,
+                      method="Radau").y[0, -1]
+    impl.select("dense", ode_shape=(1,))
+    solver = ivpsolvers.solver_dynamic(ivpsolvers.strategy_filter(ivpsolvers.prior_ibm(4), ivpsolvers.correction_ts1(ode_order=2)))
+    u0s = [np.full((B, 1), 2.0), np.zeros((B, 1))]
+    tcs = tcoeffs(vf, u0s, 4)
+    init = solver.initial_condition(tcs, 1.0)
+    save_at = np.linspace(0.0, t1, 3)
+    sol = ivpsolve.solve_adaptive_save_at(vf, init, save_at=save_at, dt0=0.01, adaptive_solver=ivpsolve.adaptive(solver, atol=tols, rtol=tols))
+    assert np.all(np.isfinite(sol.u))
+    err = np.abs(sol.u[:, -1, 0] - truth)
+    assert np.median(err[-32:]) < 1e-2 * np.median(err[:32]) and np.median(err[-32:]) < 1e-5
+    steps = sol.num_steps[:, -1]
+    assert np.median(steps[-32:]) > 5 * np.median(steps[:32])
+    idx = [3, 128, 250]
+    sub = ivpsolve.solve_adaptive_save_at(vf, solver.initial_condition([c[idx] for c in tcs], 1.0), save_at=save_at, dt0=0.01,
+                                          adaptive_solver=ivpsolve.adaptive(solver, atol=tols[idx], rtol=tols[idx]))
+    assert np.array_equal(sub.num_steps, sol.num_steps[idx]) and np.array_equal(sub.u, sol.u[idx])
