@@ -189,8 +189,10 @@ int pnode_last_step_ms(pnode_batch* h, float* ms_out);
 /* Diagnostics (dense): raw 64-bit words of a trajectory's scratch area (in-kernel cycle stamps of
  * timing-only builds, PNODE_ABLATE & 128). Never part of a result. */
 int pnode_debug_read_scratch(pnode_batch* h, int32_t b, int32_t offset_words, int32_t count, uint64_t* out);
-/* Dense model only: 1 forces the generic (non-MFMA) kernels even where the MFMA fast path applies
- * (A/B testing of the two device paths; both are HIP, neither is a CPU fallback). */
+/* Dense model only, A/B testing of the device paths (all of them HIP, none a CPU fallback): 0 = dispatch by shape
+ * (fused one-wavefront kernel for (nu+1)*d <= 32, register-resident MFMA kernels, HBM-tiled large-D kernels, generic
+ * kernels otherwise), 1 = generic kernels, 2 = large-D kernels (PNODE_EINVAL if the shape is not supported there).
+ * The environment variable PNODE_DENSE_PATH=1|2 applies the same choice to every handle created afterwards. */
 int pnode_set_generic_path(pnode_batch* h, int32_t enabled);
 /* Enables HIP-event timing of attempt_step (all models). Dense model: also record HIP events between the kernels of a step (on the handle's stream) and
  * read the durations of the last attempt, ms_out[4] = {begin, lq_input, lq, correct}. */
