@@ -92,23 +92,18 @@ __device__ __forceinline__ void factor_panel(double* rows, const PanelScratch& p
   double xr[DT];
 #pragma unroll
   for (int i = 0; i < DT; ++i) xr[i] = rows[rr * LDV + ch + 16 * i];
-  __syncthreads();
-  for (int c = 0; c < ((ablate & 1) ? 0 : kNB); ++c) {
-    double xc[DT];
-    double p0 = 0.0, p1 = 0.0, d0 = 0.0, d1 = 0.0;
+  // Householder scalars of pivot row c, computed ONCE by the group that owns the row (right after the row's last
+  // update) and published with it: beta = -sign(alpha) sqrt(alpha^2 + xx), tau = 1 + |alpha| rs, scale = 1/(alpha - beta).
+  // alpha = T0[c][c] = t0diag for every c (column c of the diagonal block is untouched before step c).
+  auto publish_scalars = [&](int c) {
+    double p0 = 0.0, p1 = 0.0;
 #pragma unroll
     for (int i = 0; i < DT; i += 2) {
-      xc[i] = rows[c * LDV + ch + 16 * i];
-      xc[i + 1] = rows[c * LDV + ch + 16 * (i + 1)];
-      p0 = fma(xc[i], xc[i], p0);
-      p1 = fma(xc[i + 1], xc[i + 1], p1);
-      d0 = fma(xr[i], xc[i], d0);
-      d1 = fma(xr[i + 1], xc[i + 1], d1);
+      p0 = fma(xr[i], xr[i], p0);
+      p1 = fma(xr[i + 1], xr[i + 1], p1);
     }
     const double xx = row16_sum(p0 + p1);
-    const double dot = row16_sum(d0 + d1);
-    const double alpha = ps.Tpp[c * kNB + c];
-    // beta = -sign(alpha) sqrt(alpha^2 + xx); tau = (beta - alpha)/beta = 1 + |alpha| rs; scale = 1/(alpha - beta)
+    const double alpha = t0diag;
     double tauc = 0.0, scale = 0.0, beta = alpha;
     if (xx != 0.0) {
       const double nrm2 = fma(alpha, alpha, xx);
@@ -118,6 +113,26 @@ __device__ __forceinline__ void factor_panel(double* rows, const PanelScratch& p
       tauc = fma(fabs(alpha), rs, 1.0);
       scale = sgn * rs * fast_rcp(tauc);
     }
+    if (ch == 0) {
+      ps.beta[c] = beta;
+      ps.tau[c] = tauc;
+      ps.scl[c] = scale;
+    }
+  };
+  if (rr == 0) publish_scalars(0);
+  __syncthreads();
+  for (int c = 0; c < ((ablate & 1) ? 0 : kNB); ++c) {
+    double xc[DT];
+    double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < DT; i += 2) {
+      xc[i] = rows[c * LDV + ch + 16 * i];
+      xc[i + 1] = rows[c * LDV + ch + 16 * (i + 1)];
+      d0 = fma(xr[i], xc[i], d0);
+      d1 = fma(xr[i + 1], xc[i + 1], d1);
+    }
+    const double dot = row16_sum(d0 + d1);
+    const double tauc = ps.tau[c], scale = ps.scl[c];
     if (rr > c) {
       if (tauc != 0.0) {
         const double tjc = ps.Tpp[rr * kNB + c];
@@ -130,13 +145,10 @@ __device__ __forceinline__ void factor_panel(double* rows, const PanelScratch& p
       if (rr == c + 1) {
 #pragma unroll
         for (int i = 0; i < DT; ++i) rows[rr * LDV + ch + 16 * i] = xr[i];
+        publish_scalars(c + 1);
       }
     } else if (rr < c) {
       if (ch == 0) Gm[rr * kNB + c] = dot;  // raw rows[rr] . rows[c]  (row rr is final)
-    } else if (ch == 0) {
-      ps.beta[c] = beta;
-      ps.tau[c] = tauc;
-      ps.scl[c] = scale;
     }
     __syncthreads();
   }
@@ -736,8 +748,8 @@ __global__ __launch_bounds__(256, 2) void dense_strip_update_mfma_kernel(DenseVi
   const size_t sB = size_t(v.B);
   double* mdst = v.mean + (size_t(arg.dst) * sB + b) * D;
   double* __restrict__ Ln = v.U + (size_t(arg.dst) * sB + b) * D * D;
-  const int st = 4 * blockIdx.x + wv;
-  if (st < DT) {
+  // one workgroup per trajectory walks all strip groups: W (64 KB) is staged once instead of once per group
+  for (int st = wv; st < DT; st += 4) {
     const int row = 16 * st + r;
     const int iblk = (16 * st) / d;
     double pr;
@@ -823,19 +835,25 @@ __global__ __launch_bounds__(256, 2) void dense_strip_update_mfma_kernel(DenseVi
           const int row2 = 16 * st + rr, c = W2 + lane + kWave * cc;
           tmp[rr * NC + cc] = (c <= row2) ? pr * T[size_t(row2) * D + c] : 0.0;
         }
+      // beyond the first 2d columns L is lower triangular like L^-: the zeros above the diagonal are structural (every
+      // kernel that writes a state factor leaves exact zeros there, the slots are zero-initialised), so only c <= row
+      // is written
 #pragma unroll
       for (int rr = 0; rr < 16; ++rr)
 #pragma unroll
-        for (int cc = 0; cc < NC; ++cc) Ln[size_t(16 * st + rr) * D + W2 + lane + kWave * cc] = tmp[rr * NC + cc];
+        for (int cc = 0; cc < NC; ++cc) {
+          const int row2 = 16 * st + rr, c = W2 + lane + kWave * cc;
+          if (c <= row2) Ln[size_t(row2) * D + c] = tmp[rr * NC + cc];
+        }
     }
     lap(4);
   }
-  if (stamp && lane == 0 && blockIdx.x == 1) {
+  if (stamp && lane == 0) {
     unsigned long long* dbg = reinterpret_cast<unsigned long long*>(v.X + size_t(b) * D * d) + 1024 + wv * 8;
     for (int i = 0; i < 8; ++i) dbg[i] = tacc[i];
   }
-  if (blockIdx.x == 0) {
-    // rows 0 .. 63 of the state are covered by this block when d <= 64: error norm over u = m[0]
+  {
+    // error norm over u = m[0] (rows 0 .. d-1 were updated above)
     __syncthreads();
     const double atol = v.atol[b], rtol = v.rtol[b];
     double part = 0.0;
@@ -905,7 +923,7 @@ static void launch_mfma(const DenseView& v, const StepArg* args, const IwpConst*
                               hipFuncAttributeMaxDynamicSharedMemorySize, int(shm2));
     attr2 = true;
   }
-  hipLaunchKernelGGL((dense_strip_update_mfma_kernel<DT, DD>), dim3((DT + 3) / 4, v.B), dim3(256), shm2, s, v, args, K);
+  hipLaunchKernelGGL((dense_strip_update_mfma_kernel<DT, DD>), dim3(1, v.B), dim3(256), shm2, s, v, args, K);
   mark(4);
 }
 
