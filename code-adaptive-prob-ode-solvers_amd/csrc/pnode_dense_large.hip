@@ -109,6 +109,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(Gemm g) {
     stash(ra[u], rb[u]);
     __syncthreads();
     fetch(kk + PD * KS < klast ? kk + PD * KS : klast, ra[u], rb[u]);  // (past the end: a harmless re-read of the last tile)
+    __builtin_amdgcn_sched_barrier(0);  // keep the loads above the MFMAs (they would be sunk next to the next stash)
 #pragma unroll
     for (int k4 = 0; k4 < 4; ++k4) {
       double a[2], bb[2];
@@ -127,6 +128,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(Gemm g) {
   }
   const double* C0 = g.C0 ? g.C0 + long(b) * g.sC0 : nullptr;
   double* C = g.C + (g.offC ? g.offC[b] : long(b) * g.sC);
+  // epilogue in two phases (all C0 loads in flight, then the stores): C0 may alias C element by element (in-place
+  // updates), which would otherwise serialise every load behind the previous store
+  double4_t c0v[2][2];
 #pragma unroll
   for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -134,11 +138,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(Gemm g) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int row = m0 + wm * 32 + tm * 16 + 4 * q + gq, col = n0 + wn * 32 + tn * 16 + r;
-        if (row < g.M && col < g.N) {
-          double val = g.alpha * acc[tm][tn][q];
-          if (C0) val = fma(g.beta, C0[long(row) * g.ldc0 + col], val);
-          C[long(row) * g.ldc + col] = val;
-        }
+        c0v[tm][tn][q] = (C0 && row < g.M && col < g.N) ? C0[long(row) * g.ldc0 + col] : 0.0;
+      }
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = m0 + wm * 32 + tm * 16 + 4 * q + gq, col = n0 + wn * 32 + tn * 16 + r;
+        if (row < g.M && col < g.N) C[long(row) * g.ldc + col] = fma(g.beta, c0v[tm][tn][q], g.alpha * acc[tm][tn][q]);
       }
 }
 
