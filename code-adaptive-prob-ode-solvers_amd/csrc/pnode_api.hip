@@ -317,7 +317,8 @@ int pnode_create(const pnode_config* cfg, pnode_batch** out) {
     ALLOC(v.sig_new, B);
     {
       const int DT = int(D) / 16;
-      if (v.ts1 && d % 32 == 0 && D % 128 == 0 && (DT == 8 || DT == 16 || DT == 32 || DT == 48 || DT == 64)) {
+      (void)DT;
+      if (v.ts1 && d % 32 == 0 && D % 64 == 0 && D >= 64 && D <= 1024) {
         ALLOC(v.lgG, B * v.mr_rows * D * 128);
         ALLOC(v.lgW, B * v.mr_rows * D * 128);
         ALLOC(v.lgTf, B * 4 * 32 * 32);

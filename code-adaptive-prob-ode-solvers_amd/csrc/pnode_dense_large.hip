@@ -1,4 +1,4 @@
-// Dense EKF1 for LARGE state dimensions (D = (nu+1) d in {128, 256, 512, 768, 1024}, d % 32 == 0): BASELINE config 5
+// Dense EKF1 for LARGE state dimensions (D = (nu+1) d a multiple of 64 up to 1024, d % 32 == 0): BASELINE config 5
 // (Brusselator N = 128, d = 256, nu = 3, D = 1024 — "MFMA Jacobian x cov path"). One trajectory's factor (8 MB at
 // D = 1024) fits neither registers nor LDS, so the step is a sequence of batched, HBM/L2-tiled kernels:
 //   * gemm_kernel        : C = beta C0 + alpha A op(B), fp64 MFMA 16x16x4, 64x64 or 128x32 tiles staged through LDS,
@@ -347,9 +347,9 @@ __global__ __launch_bounds__(256) void tf_outer_kernel(const double* __restrict_
   const int b = blockIdx.x;
   if (act && !act[b]) return;
   const int OBs = nb * PB, tid = threadIdx.x;
-  const double* tp = Tfp + size_t(b) * nb * PB * PB;
-  const double* G = Gram + size_t(b) * OBs * OBs;
-  double* X = Tfo + size_t(b) * OBs * OBs;
+  const double* tp = Tfp + size_t(b) * 4 * PB * PB;  // fixed per-trajectory strides (at most four panels per outer block)
+  const double* G = Gram + size_t(b) * 128 * 128;
+  double* X = Tfo + size_t(b) * 128 * 128;
   for (int e = tid; e < OBs * OBs; e += 256) {
     const int r = e / OBs, c = e % OBs;
     X[e] = (r / PB == c / PB) ? tp[(r / PB) * PB * PB + (r % PB) * PB + (c % PB)] : 0.0;
@@ -797,19 +797,30 @@ static void launch_panel(const DenseView& v, int p0, double* Tf, int tf_stride, 
 // T[:, blk] -= W, Mt -= W V  -- a quarter of the trailing-matrix traffic of panel-by-panel updates.
 static void blocked_lq(const DenseView& v, int rows_total, hipStream_t s) {
   const int B = v.B, D = v.D;
-  const int OB = D < 128 ? D : 128, nb = OB / PB;
   const long sDD = long(v.mr_rows) * D * D;
-  const long sG = long(rows_total) * OB;
-  const int tfs = nb * PB * PB;
-  for (int o0 = 0; o0 < D; o0 += OB) {
+  const long sG = long(rows_total) * 128;
+  const int tfs = 4 * PB * PB;  // panel factors of one outer block (at most four panels)
+  for (int o0 = 0; o0 < D; o0 += 128) {
+    const int OB = D - o0 < 128 ? D - o0 : 128, nb = OB / PB;  // (the last outer block may be shorter: D % 128 in {0, 64})
     for (int pi = 0; pi < nb; ++pi) {
       const int p0 = o0 + pi * PB;
       double* Tf = v.lgTf + size_t(pi) * PB * PB;
-      switch (D / 16) {
-        case 8: launch_panel<8>(v, p0, Tf, tfs, s); break;
-        case 16: launch_panel<16>(v, p0, Tf, tfs, s); break;
-        case 32: launch_panel<32>(v, p0, Tf, tfs, s); break;
-        case 48: launch_panel<48>(v, p0, Tf, tfs, s); break;
+      switch (D / 64) {
+        case 1: launch_panel<4>(v, p0, Tf, tfs, s); break;
+        case 2: launch_panel<8>(v, p0, Tf, tfs, s); break;
+        case 3: launch_panel<12>(v, p0, Tf, tfs, s); break;
+        case 4: launch_panel<16>(v, p0, Tf, tfs, s); break;
+        case 5: launch_panel<20>(v, p0, Tf, tfs, s); break;
+        case 6: launch_panel<24>(v, p0, Tf, tfs, s); break;
+        case 7: launch_panel<28>(v, p0, Tf, tfs, s); break;
+        case 8: launch_panel<32>(v, p0, Tf, tfs, s); break;
+        case 9: launch_panel<36>(v, p0, Tf, tfs, s); break;
+        case 10: launch_panel<40>(v, p0, Tf, tfs, s); break;
+        case 11: launch_panel<44>(v, p0, Tf, tfs, s); break;
+        case 12: launch_panel<48>(v, p0, Tf, tfs, s); break;
+        case 13: launch_panel<52>(v, p0, Tf, tfs, s); break;
+        case 14: launch_panel<56>(v, p0, Tf, tfs, s); break;
+        case 15: launch_panel<60>(v, p0, Tf, tfs, s); break;
         default: launch_panel<64>(v, p0, Tf, tfs, s); break;
       }
       const int j0 = p0 + PB;
@@ -832,14 +843,15 @@ static void blocked_lq(const DenseView& v, int rows_total, hipStream_t s) {
     double* Vo = v.M + size_t(o0) * D;        // OB scaled reflector rows
     double* Mb = v.M + size_t(j0) * D;
     double* Tb = v.R + size_t(j0) * D + o0;
-    Gemm gg{Vo, Vo, nullptr, v.lgGram, sDD, sDD, 0, long(OB) * OB, D, D, 0, OB, OB, OB, D, 1.0, 0.0, v.act, nullptr};
+    const long sT = 128 * 128;
+    Gemm gg{Vo, Vo, nullptr, v.lgGram, sDD, sDD, 0, sT, D, D, 0, OB, OB, OB, D, 1.0, 0.0, v.act, nullptr};
     gemm(s, B, true, gg);  // Gram = V V^T
     hipLaunchKernelGGL(tf_outer_kernel, dim3(B), dim3(256), 0, s, v.lgTf, v.lgGram, v.lgTfo, nb, v.act);
     Gemm g1{Mb, Vo, Tb, v.lgG, sDD, sDD, sDD, sG, D, D, D, OB, rows, OB, D, 1.0, 1.0, v.act, nullptr};
     gemm(s, B, true, g1);
-    Gemm g2{v.lgG, v.lgTfo, nullptr, v.lgW, sG, long(OB) * OB, 0, sG, OB, OB, 0, OB, rows, OB, OB, 1.0, 0.0, v.act, nullptr};
+    Gemm g2{v.lgG, v.lgTfo, nullptr, v.lgW, sG, sT, 0, sG, OB, OB, 0, OB, rows, OB, OB, 1.0, 0.0, v.act, nullptr};
     gemm(s, B, false, g2);
-    Gemm g3{v.lgG, v.lgTfo, Tb, Tb, sG, long(OB) * OB, sDD, sDD, OB, OB, D, D, rows, OB, OB, -1.0, 1.0, v.act, nullptr};
+    Gemm g3{v.lgG, v.lgTfo, Tb, Tb, sG, sT, sDD, sDD, OB, OB, D, D, rows, OB, OB, -1.0, 1.0, v.act, nullptr};
     gemm(s, B, false, g3);
     Gemm g4{v.lgW, Vo, Mb, Mb, sG, sDD, sDD, sDD, OB, D, D, D, rows, D, OB, -1.0, 1.0, v.act, nullptr};
     gemm(s, B, false, g4);
@@ -879,8 +891,7 @@ void dense_large_fp_backward(const DenseView& v, const FpArg* fa, const IwpConst
 }
 
 bool dense_large_supported(const DenseView& v) {
-  const int DT = v.D / 16;
-  return v.ts1 && v.d % 32 == 0 && v.D % 128 == 0 && (DT == 8 || DT == 16 || DT == 32 || DT == 48 || DT == 64) && v.lgG != nullptr;
+  return v.ts1 && v.d % 32 == 0 && v.D % 64 == 0 && v.D >= 64 && v.D <= 1024 && v.lgG != nullptr;
 }
 
 // Filter: D beyond the register-resident MFMA path. Fixed-point smoother: every supported shape (the register-resident

@@ -259,19 +259,24 @@ def test_dense_mfma_path_matches_oracle_and_generic(hip_lib, N, nu):
     slow.close()
 
 
-@pytest.mark.parametrize("N,nu", [(16, 3), (32, 3), (64, 3)])
+@pytest.mark.parametrize("N,nu", [(16, 3), (32, 3), (64, 3), (16, 5), (48, 2)])
 def test_dense_large_path_matches_oracle_and_mfma_path(hip_lib, N, nu):
     """The HBM-tiled large-D kernels (batched MFMA GEMMs, blocked LQ / Cholesky / triangular solve; the path BASELINE
     config 5 takes at D = 1024) forced at sizes the oracle steps through quickly: several steps with per-trajectory
     step sizes, a rejected step (destination slots drift apart) and an inactive trajectory, against the oracle and the
-    default path."""
+    default path. (16, 5): D = 192 = 128 + 64, a shorter last outer block; (48, 2): d = 96, D = 288 is not a multiple of
+    64 -> not supported there, the generic kernels are compared instead.)"""
     vf = V.brusselator(N)
     B = 3
     y0 = np.stack([brusselator_y0(N, ph) for ph in (0.0, 0.4, 1.1)])
     tc = tcoeffs(vf, [y0], nu)
     tc_arr = np.stack(tc, axis=1)
     large = _dense_batch(vf, nu, "ts1", B)
-    large.set_generic_path(2)
+    if ((nu + 1) * vf.d) % 64 == 0:
+        large.set_generic_path(2)
+    else:
+        with pytest.raises(ValueError):
+            large.set_generic_path(2)
     ref = _dense_batch(vf, nu, "ts1", B)
     for bt in (large, ref):
         bt.set_initial(tc_arr, np.zeros(B), np.ones(B))
@@ -313,9 +318,10 @@ def test_dense_large_path_matches_oracle_and_mfma_path(hip_lib, N, nu):
 
 
 def test_dense_maximum_size_generic_path(hip_lib):
-    """BASELINE config 5 size (Brusselator N=128: d=256, D=1024; default: the large-D path) and an un-instantiated tile
-    count (N=64, nu=4: D=640, generic dense kernels); two steps against the oracle."""
-    for N, nu in ((128, 3), (64, 4)):
+    """BASELINE config 5 size (Brusselator N=128: d=256, D=1024), N=64, nu=4 (D=640) and N=48, nu=3 (d=96, D=384): shapes
+    beyond the register-resident kernels, on the large-D path by default; N=24, nu=3 (d=48: generic kernels). Two steps
+    against the oracle."""
+    for N, nu in ((128, 3), (64, 4), (48, 3), (24, 3)):
         vf = V.brusselator(N)
         tc = tcoeffs(vf, [brusselator_y0(N)[None]], nu)
         batch = _dense_batch(vf, nu, "ts1", 1)
