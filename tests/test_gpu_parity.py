@@ -214,6 +214,37 @@ def test_dense_steps_match_oracle(hip_lib, case, path):
     batch.close()
 
 
+@pytest.mark.parametrize("case", ["small", "mfma", "large", "generic"])
+def test_dense_inactive_and_rejected_trajectories_untouched(hip_lib, case):
+    """Every dense device path: an inactive trajectory keeps its state and error slot bit for bit, a rejected attempt
+    leaves STEP_FROM intact (the next attempt from the same state reproduces the same numbers), an accepted one advances."""
+    if case == "small":
+        vf, nu, y0 = V.rigid_body(), 3, np.array([[1.0, 0.0, 0.9], [0.9, 0.1, 0.8], [1.1, -0.1, 1.0]])
+    else:
+        N = {"mfma": 16, "large": 48, "generic": 12}[case]
+        vf, nu, y0 = V.brusselator(N), 3, np.stack([brusselator_y0(N, ph) for ph in (0.0, 0.3, 0.6)])
+    B = 3
+    tc = np.stack(tcoeffs(vf, [y0], nu), axis=1)
+    batch = _dense_batch(vf, nu, "ts1", B)
+    batch.set_initial(tc, np.zeros(B), np.ones(B))
+    batch.set_tolerances(1e-5, 1e-5)
+    err = np.full(B, -1.0)
+    batch.attempt_step(np.full(B, 0.01), np.array([1, 0, 1], np.uint8), err)
+    assert err[1] == -1.0 and err[0] > 0 and err[2] > 0
+    e_first = err.copy()
+    batch.commit(np.array([1, 0, 0], np.uint8))   # trajectory 2: rejected
+    t, steps = batch.read_time()
+    assert list(steps) == [1, 0, 0] and t[0] == 0.01 and t[1] == 0.0 and t[2] == 0.0
+    means = batch.read_mean(0)
+    assert np.array_equal(means[1], tc[1]) and np.array_equal(means[2], tc[2])
+    assert not np.array_equal(means[0], tc[0])
+    assert np.all(batch.read_factor(0)[1] == 0.0) and np.all(batch.read_factor(0)[2] == 0.0)
+    # the rejected trajectory repeats the attempt from the untouched state: identical error estimate
+    batch.attempt_step(np.full(B, 0.01), np.array([0, 0, 1], np.uint8), err)
+    assert err[2] == e_first[2]
+    batch.close()
+
+
 @pytest.mark.parametrize("N,nu", [(16, 3), (32, 3), (16, 5), (32, 4)])
 def test_dense_mfma_path_matches_oracle_and_generic(hip_lib, N, nu):
     """The MFMA-tiled LQ / measurement-update kernels (d % 16 == 0) against the oracle and against the
