@@ -83,10 +83,10 @@ def main():
     tols = 10.0 ** np.linspace(-2, -8, B)
     run("C2 vdp mu=1e3 EKF1 sweep", vf, [np.tile(u0[0], (B, 1)), np.tile(u0[1], (B, 1))], t0, t1, model="dense", corr="ts1",
         strategy="filter", nu=4, atol=tols, rtol=tols, dt0=0.01)
-    # C3a: rigid body d=3, t in [0, 50], nu = 2..5 isotropic fixedpoint, 256 tolerances each
+    # C3a: rigid body d=3, t in [0, 50], nu = 2..5 isotropic fixedpoint, 1024 tolerances each
     vf, u0, (t0, t1), _ = ivps.rigid_body(time_span=(0.0, 50.0))
     tr = solve_ivp(lambda t, y: vf(y), (t0, t1), u0[0], rtol=1e-13, atol=1e-13, method="LSODA").y[:, -1]
-    B = 256
+    B = 1024  # BASELINE config 3: batch = 1024 on one GPU
     rt = 10.0 ** np.linspace(-1, -7, B)
     for nu in (2, 3, 4, 5):
         run(f"C3 rigid body nu={nu} sweep", vf, [np.tile(u0[0], (B, 1))], t0, t1, model="isotropic", corr="ts0",
@@ -113,14 +113,18 @@ def main():
     run("C4 brusselator iso EKF0 nu=4 fixedpoint 200 ckpts", vf, [y0], 0.0, 10.0, model="isotropic", corr="ts0",
         strategy="fixedpoint", nu=4, atol=1e-8, rtol=1e-8, dt0=0.01, num_save=200, device_controller=True)
     vf, u0, (t0, t1), _ = ivps.rigid_body(time_span=(0.0, 50.0))
-    run("C3 rigid body nu=3 sweep", vf, [np.tile(u0[0], (256, 1))], t0, t1, model="isotropic", corr="ts0",
+    run("C3 rigid body nu=3 sweep", vf, [np.tile(u0[0], (B, 1))], t0, t1, model="isotropic", corr="ts0",
         strategy="fixedpoint", nu=3, atol=1e-3 * rt, rtol=rt, dt0=0.1, device_controller=True)
+    vf, u0, (t0, t1) = ivps.pleiades_2nd()
+    run("C3 pleiades nu=3 sweep", vf, [np.tile(u0[0], (B, 1)), np.tile(u0[1], (B, 1))], t0, t1, model="isotropic",
+        corr="ts0", strategy="fixedpoint", nu=3, atol=1e-3 * rt, rtol=rt, dt0=0.01, device_controller=True)
     vf, u0, (t0, t1), _ = ivps.van_der_pol_first_order(1.0)
     run("C1 vdp mu=1 (single)", vf, [u0[0]], t0, t1, model="isotropic", corr="ts0", strategy="filter", nu=3,
         atol=1e-6, rtol=1e-6, dt0=0.1, device_controller=True)
     vf, u0, (t0, t1) = ivps.van_der_pol(1e3)
     run("C2 vdp mu=1e3 EKF1 sweep", vf, [np.tile(u0[0], (256, 1)), np.tile(u0[1], (256, 1))], t0, t1, model="dense", corr="ts1",
         strategy="filter", nu=4, atol=tols, rtol=tols, dt0=0.01, device_controller=True)
+    config5()
 
 
 if __name__ == "__main__":
