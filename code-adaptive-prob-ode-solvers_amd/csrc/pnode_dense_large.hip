@@ -256,7 +256,7 @@ __global__ __launch_bounds__(1024) void lq_panel_kernel(DenseView v, int p0, dou
   __syncthreads();
   if (w == 0) publish(0, x0);
   __syncthreads();
-  for (int c = 0; c < ((v.ablate & 1) ? 0 : PB); ++c) {
+  for (int c = 0; c < PB; ++c) {
     const double* pc = piv[c & 1];
     double xc[NC];
     double d0 = 0.0, d1 = 0.0;
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(1024) void lq_panel_kernel(DenseView v, int p0, dou
     Af[tid] = ((ei == ej) ? 1.0 : 0.0) - nij;
     __syncthreads();
 #pragma unroll 1
-    for (int it = 0; it < ((v.ablate & 2) ? 0 : 4); ++it) {
+    for (int it = 0; it < 4; ++it) {
       double q = 0.0;
 #pragma unroll 8
       for (int m = 0; m < PB; ++m) q = fma(Nm[ei * PB + m], Nm[m * PB + ej], q);
