@@ -636,6 +636,31 @@ def test_uncalibrated_solver_matches_oracle(hip_lib, model):
         assert relmax(cov1, cov0 * (scales[1] / scales[0]) ** 2) < 1e-6
 
 
+@pytest.mark.parametrize("path", [0, 2])
+def test_uncalibrated_dense_on_the_mfma_and_large_paths(hip_lib, path, monkeypatch):
+    """calibrate="none" with the dense model at Brusselator N=16 (d=32, D=128): the register-resident MFMA kernels
+    (default) and the large-D kernels (forced), adaptive solve with the fixed output scale against the oracle."""
+    if path:
+        monkeypatch.setenv("PNODE_DENSE_PATH", str(path))
+    N = 16
+    vf = V.brusselator(N)
+    impl.select("dense", ode_shape=(2 * N,))
+    solver = ivpsolvers.solver(ivpsolvers.strategy_filter(ivpsolvers.prior_ibm(3), ivpsolvers.correction_ts1()))
+    scales = np.array([1.0, 9.0])
+    y0 = np.stack([brusselator_y0(N, 0.0), brusselator_y0(N, 0.5)])
+    tcs = tcoeffs(vf, [y0], 3)
+    init = solver.initial_condition(tcs, output_scale=scales)
+    save_at = np.linspace(0.0, 0.5, 3)
+    sol = ivpsolve.solve_adaptive_save_at(vf, init, save_at=save_at, dt0=0.01, adaptive_solver=ivpsolve.adaptive(solver, atol=1e-5, rtol=1e-5))
+    cfg = po.SolverConfig(nu=3, model="dense", correction="ts1", strategy="filter", calibration="none")
+    for b in range(2):
+        osol = po.solve_adaptive_save_at(cfg, po.AdaptiveConfig(1e-5, 1e-5), oracle_problem(vf),
+                                         po.initial_state(cfg, [c[b] for c in tcs], 0.0, scales[b]), save_at, 0.01)
+        assert np.array_equal(sol.num_steps[b], osol.num_steps), b
+        assert relmax(sol.u[b], osol.u) < 1e-9, b
+    assert np.allclose(sol.output_scale, scales)
+
+
 def test_edge_cases_single_checkpoint_ragged_save_at_and_nan_propagation(hip_lib):
     """B = 1 with one checkpoint; per-trajectory (ragged) save_at grids; a trajectory whose vector field blows up
     must come back as NaN/flagged without disturbing its batch neighbours (the reference propagates NaNs,
