@@ -244,7 +244,20 @@ def main():
             lq_ms = phase[2] / K
             flops = algorithmic_flops_lq(D) * B
             achieved = flops / (lq_ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+            # the north star also asks for the fraction of the HBM roofline: whole step (all dense kernels), algorithmic bytes
+            # (state factor read + written once, 2 * 8 * D^2 per trajectory) and the bytes the PMC pass measured
+            step_ms = dev_ms / K
+            alg_bytes = 2.0 * 8.0 * D * D * B
+            meas_bytes = measured_traffic("dense_", B)
+            hbm = {"peak_GBps": HBM_PEAK_GBS, "streaming_ceiling_GBps": 4000.0,
+                   "streaming_ceiling_source": "scripts/hbm_probe.hip: read+write in the strip layout, no compute",
+                   "algorithmic_bytes_per_step": alg_bytes, "algorithmic_GBps": alg_bytes / (step_ms * 1e-3) / 1e9,
+                   "algorithmic_frac": alg_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                   "measured_bytes_per_step": meas_bytes}
+            if meas_bytes:
+                hbm["measured_GBps"] = meas_bytes / (step_ms * 1e-3) / 1e9
+                hbm["measured_frac"] = hbm["measured_GBps"] / HBM_PEAK_GBS
+            out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "hbm": hbm,
                                "frac": achieved / FP64_PEAK_TFLOPS, "traffic": measured_traffic("dense_lq2_mfma_kernel", B),
                                "traffic_source": "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
                                "kernel": "dense_lq2_mfma_kernel<16,true> + <16,false> (one LQ, two launches)",
