@@ -295,9 +295,10 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
       tprev = now;
     }
   };
+  bool carried = false;  // the 32 rows of this pass's panels were left in Vx by the previous pass (no HBM round trip)
   for (int P = FIRST ? 0 : first_pass; P < (FIRST ? 1 : DT / 2); ++P) {
     const int c0 = 2 * kNB * P;
-    {
+    if (!carried) {
       constexpr int NL = 2 * kNB * D / 256;
       double tmp[NL];
       if constexpr (fused) {
@@ -372,10 +373,9 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
     lap(4);
     // ---- trailing strips: both panels in one pass over the rows
     const int nstrips = (v.ablate & 2) ? 0 : DT - 2 * (P + 1);
-    for (int st = wv; st < nstrips; st += 4) {
+    auto load_strip = [&](int st, double (&X)[4 * DT]) {
       const int j0 = c0 + 2 * kNB + kNB * st;
-      double* __restrict__ rowp = Mt + size_t(j0 + r) * D + 16 * g;
-      double X[4 * DT];
+      const double* __restrict__ rowp = Mt + size_t(j0 + r) * D + 16 * g;
       if constexpr (fused) {
         const int ib = j0 / d, q = (j0 + r) % d;
 #pragma unroll
@@ -403,9 +403,16 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
           X[16 * T4 + e] = t2.x;
           X[16 * T4 + e + 1] = t2.y;
         }
+    };
+    auto apply_both = [&](int st, double (&X)[4 * DT]) {
+      const int j0 = c0 + 2 * kNB + kNB * st;
       double* Trow = T + size_t(j0 + r) * D + c0;
       apply_panel_to_strip<DT, LDV>(X, VA, psA.Tf, psA.scl, t0_tile(j0, c0), Trow, r, g);
       apply_panel_to_strip<DT, LDV>(X, VB, psB.Tf, psB.scl, t0_tile(j0, c0 + kNB), Trow + kNB, r, g);
+    };
+    auto store_strip = [&](int st, const double (&X)[4 * DT]) {
+      const int j0 = c0 + 2 * kNB + kNB * st;
+      double* __restrict__ rowp = Mt + size_t(j0 + r) * D + 16 * g;
 #pragma unroll
       for (int T4 = 0; T4 < DT / 4; ++T4)
 #pragma unroll
@@ -415,9 +422,29 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
           t2.y = X[16 * T4 + e + 1];
           *reinterpret_cast<double2*>(rowp + 64 * T4 + e) = t2;
         }
+    };
+    // Strips 0 and 1 are the panels of the NEXT pass: wavefronts 0 and 1 process them last, keep them in registers
+    // over the end-of-pass barrier and drop them straight into Vx, instead of a write to and a re-read from HBM.
+    const bool carry = !FIRST && nstrips >= 2;
+    const bool keeper = carry && wv < 2;
+    const int nmine = nstrips > wv ? (nstrips - wv + 3) / 4 : 0;
+    double X[4 * DT];
+    for (int it = 0; it < nmine; ++it) {
+      const bool last = it + 1 == nmine;
+      const int st = keeper ? (last ? wv : wv + 4 * (it + 1)) : wv + 4 * it;
+      load_strip(st, X);
+      apply_both(st, X);
+      if (!(keeper && last)) store_strip(st, X);
     }
     lap(5);
-    __syncthreads();
+    __syncthreads();  // every wavefront is done with the reflectors in Vx
+    if (keeper) {
+#pragma unroll
+      for (int T4 = 0; T4 < DT / 4; ++T4)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) Vx[(kNB * wv + r) * LDV + 64 * T4 + 16 * g + e] = X[16 * T4 + e];
+    }
+    carried = carry;  // (the barrier at the top of the next pass publishes the rows)
     lap(6);
   }
   if (stamp && lane == 0) {
