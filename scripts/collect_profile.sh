@@ -5,6 +5,7 @@ set -e
 TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+rm -rf $OUT
 mkdir -p $OUT
 ARGS="bench.py --steps 20 --warmup 15 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.json 2> $OUT/trace.err

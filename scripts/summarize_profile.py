@@ -7,6 +7,7 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
 
 
@@ -16,7 +17,7 @@ def short(name):
 
 def main(out):
     res = collections.OrderedDict()
-    stats = glob.glob(f"{out}/trace/*/*kernel_stats.csv")
+    stats = sorted(glob.glob(f"{out}/trace/*/*kernel_stats.csv"), key=os.path.getmtime, reverse=True)  # newest run
     if stats:
         for r in csv.DictReader(open(stats[0])):
             k = short(r["Name"])
@@ -25,7 +26,7 @@ def main(out):
                 res[k]["calls"] = int(r["Calls"])
                 res[k]["pct"] = float(r["Percentage"])
     for tag in ("sq", "fetch", "write"):
-        files = glob.glob(f"{out}/{tag}/*/*counter_collection.csv")
+        files = sorted(glob.glob(f"{out}/{tag}/*/*counter_collection.csv"), key=os.path.getmtime, reverse=True)
         if not files:
             continue
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
