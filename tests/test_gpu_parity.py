@@ -731,3 +731,52 @@ def test_user_vector_field_escape_hatch(hip_lib):
             # single accept/reject decision to differ
             assert np.max(np.abs(sol.num_steps[b] - osol.num_steps)) <= 2
             assert relmax(sol.u[b], osol.u) < 1e-6
+
+
+@pytest.mark.parametrize("case", ["small_rigid", "small_vdp2", "mfma16", "mfma32", "large16", "large48"])
+def test_differential_fuzz_fast_paths_against_generic_kernels(hip_lib, case):
+    """Seeded differential run of every fast dense path against the generic kernels: 25 attempts with random step sizes,
+    random activity masks and random accept/reject decisions (slots drift apart, rejected states are re-used). The two
+    handles must agree on every error estimate, mean and covariance throughout."""
+    rng = np.random.default_rng(20260104)
+    B = 6
+    if case == "small_rigid":
+        vf, nu, u0s, dt_scale = V.rigid_body(), 3, [np.array([1.0, 0.0, 0.9]) + 0.05 * rng.standard_normal((B, 3))], 0.05
+    elif case == "small_vdp2":
+        vf, nu, u0s, dt_scale = (V.van_der_pol_order2(20.0), 4, [2.0 + 0.1 * rng.standard_normal((B, 1)), 0.1 * rng.standard_normal((B, 1))],
+                                 0.005)
+    else:
+        N = int(case[-2:])
+        vf, nu, dt_scale = V.brusselator(N), 3, 0.01
+        u0s = [np.stack([brusselator_y0(N, ph) for ph in rng.uniform(0, 2, B)])]
+    tc = np.stack(tcoeffs(vf, u0s, nu), axis=1)
+    fast = _dense_batch(vf, nu, "ts1", B)
+    if case.startswith("large"):
+        fast.set_generic_path(2)
+    slow = _dense_batch(vf, nu, "ts1", B)
+    slow.set_generic_path(1)
+    for bt in (fast, slow):
+        bt.set_initial(tc, np.zeros(B), np.ones(B))
+        bt.set_tolerances(1e-5, 1e-5)
+    ef, es = np.zeros(B), np.zeros(B)
+    for it in range(25):
+        dts = dt_scale * rng.uniform(0.3, 2.0, B)
+        act = (rng.uniform(size=B) < 0.8).astype(np.uint8)
+        if it == 0:
+            act[:] = 1
+        acc = (act.astype(bool) & (rng.uniform(size=B) < 0.7)).astype(np.uint8)
+        fast.attempt_step(dts, act, ef)
+        slow.attempt_step(dts, act, es)
+        m = act.astype(bool)
+        assert np.all(np.abs(ef[m] - es[m]) <= 1e-6 * np.abs(es[m])), (it, ef, es)
+        fast.commit(acc)
+        slow.commit(acc)
+        mf, ms = fast.read_mean(0), slow.read_mean(0)
+        Rf, Rs = fast.read_factor(0), slow.read_factor(0)
+        for b in range(B):
+            assert relmax(mf[b, 0], ms[b, 0]) < 1e-10, (it, b)
+            assert relmax(mf[b, 1], ms[b, 1]) < 1e-8, (it, b)
+            cf, cs = Rf[b].T @ Rf[b], Rs[b].T @ Rs[b]
+            assert np.max(np.abs(cf - cs)) <= 1e-6 * max(np.max(np.abs(cs)), 1e-300), (it, b)
+    fast.close()
+    slow.close()
