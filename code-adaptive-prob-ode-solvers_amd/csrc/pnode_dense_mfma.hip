@@ -191,7 +191,8 @@ __device__ __forceinline__ void factor_panel(double* rows, const PanelScratch& p
 template <int DT, int LDV>
 __device__ __forceinline__ void apply_panel_to_strip(double (&X)[4 * DT], const double* __restrict__ Vp,
                                                      const double* __restrict__ Tfp, const double* __restrict__ sclp,
-                                                     double4_t t0v, double* __restrict__ Tout, int r, int g) {
+                                                     double4_t t0v, double* __restrict__ Tout, double out_scale, int r,
+                                                     int g) {
   double4_t a0 = {0.0, 0.0, 0.0, 0.0}, a1 = a0, a2 = a0, a3 = a0;
   double4_t sc;
 #pragma unroll
@@ -213,7 +214,7 @@ __device__ __forceinline__ void apply_panel_to_strip(double (&X)[4 * DT], const 
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) w4 = MFMA64(Tfp[(4 * kk + g) * kNB + r], acc[kk], w4);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) Tout[g + 4 * q] = t0v[q] - w4[q];
+  for (int q = 0; q < 4; ++q) Tout[g + 4 * q] = out_scale * (t0v[q] - w4[q]);
   w4 = w4 * sc;  // the update below multiplies by the unscaled rows
   const int coff = 16 * (r & 3) + (r >> 2);
 #pragma unroll
@@ -295,9 +296,21 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
       tprev = now;
     }
   };
+  // Columns >= 2d of L^- are not touched by the measurement update (F = H L^- has 2d non-zero columns): the passes
+  // that produce them write p_row * T straight into the destination slot of the state factor, so the strip-update
+  // kernel neither reads nor copies them.
+  double* __restrict__ Ldst = v.U + (size_t(sarg.dst) * v.B + b) * D * D;
+  __shared__ double pS[kMaxN];
+  if (tid == 0) {
+    double pl[kMaxN], pil[kMaxN];
+    precond_rt(nn, sarg.dt, K, pl, pil);
+    for (int i = 0; i < kMaxN; ++i) pS[i] = (i < nn) ? pl[i] : 0.0;
+  }
+  __syncthreads();
   bool carried = false;  // the 32 rows of this pass's panels were left in Vx by the previous pass (no HBM round trip)
   for (int P = FIRST ? 0 : first_pass; P < (FIRST ? 1 : DT / 2); ++P) {
     const int c0 = 2 * kNB * P;
+    const bool direct = c0 >= 2 * d;  // (2d is a multiple of 32: a pass is either all below or all beyond)
     if (!carried) {
       constexpr int NL = 2 * kNB * D / 256;
       double tmp[NL];
@@ -343,7 +356,11 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
       for (int kk = 0; kk < 4; ++kk) w4 = MFMA64(psA.Tf[(4 * kk + g) * kNB + r], acc[kk], w4);
       if (wv == 0) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) T[size_t(c0 + kNB + r) * D + c0 + g + 4 * q] = t0v[q] - w4[q];
+        for (int q = 0; q < 4; ++q) {
+          const size_t o = size_t(c0 + kNB + r) * D + c0 + g + 4 * q;
+          if (direct) Ldst[o] = pS[(c0 + kNB + r) / d] * (t0v[q] - w4[q]);
+          else T[o] = t0v[q] - w4[q];
+        }
       }
       w4 = w4 * sc;
       __syncthreads();  // every wave has read all of B before anyone overwrites its tiles
@@ -366,8 +383,14 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
     {
       const int i = tid >> 4, j = tid & 15;
       if (j <= i) {
-        T[size_t(c0 + i) * D + c0 + j] = psA.Tpp[i * kNB + j];
-        T[size_t(c0 + kNB + i) * D + c0 + kNB + j] = psB.Tpp[i * kNB + j];
+        const size_t oa = size_t(c0 + i) * D + c0 + j, ob = size_t(c0 + kNB + i) * D + c0 + kNB + j;
+        if (direct) {
+          Ldst[oa] = pS[(c0 + i) / d] * psA.Tpp[i * kNB + j];
+          Ldst[ob] = pS[(c0 + kNB + i) / d] * psB.Tpp[i * kNB + j];
+        } else {
+          T[oa] = psA.Tpp[i * kNB + j];
+          T[ob] = psB.Tpp[i * kNB + j];
+        }
       }
     }
     lap(4);
@@ -406,9 +429,10 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
     };
     auto apply_both = [&](int st, double (&X)[4 * DT]) {
       const int j0 = c0 + 2 * kNB + kNB * st;
-      double* Trow = T + size_t(j0 + r) * D + c0;
-      apply_panel_to_strip<DT, LDV>(X, VA, psA.Tf, psA.scl, t0_tile(j0, c0), Trow, r, g);
-      apply_panel_to_strip<DT, LDV>(X, VB, psB.Tf, psB.scl, t0_tile(j0, c0 + kNB), Trow + kNB, r, g);
+      double* Trow = (direct ? Ldst : T) + size_t(j0 + r) * D + c0;
+      const double osc = direct ? pS[(j0 + r) / d] : 1.0;
+      apply_panel_to_strip<DT, LDV>(X, VA, psA.Tf, psA.scl, t0_tile(j0, c0), Trow, osc, r, g);
+      apply_panel_to_strip<DT, LDV>(X, VB, psB.Tf, psB.scl, t0_tile(j0, c0 + kNB), Trow + kNB, osc, r, g);
     };
     auto store_strip = [&](int st, const double (&X)[4 * DT]) {
       const int j0 = c0 + 2 * kNB + kNB * st;
@@ -851,28 +875,7 @@ __global__ __launch_bounds__(256, 2) void dense_strip_update_mfma_kernel(DenseVi
           *reinterpret_cast<double2*>(lrow + 64 * T4 + e) = t2;
         }
     }
-    // the remaining columns of these 16 rows are plain (scaled) copies of the triangular factor
-    {
-      constexpr int NC = (D - W2) / kWave;  // column chunks per row
-      double tmp[16 * NC];
-#pragma unroll
-      for (int rr = 0; rr < 16; ++rr)
-#pragma unroll
-        for (int cc = 0; cc < NC; ++cc) {
-          const int row2 = 16 * st + rr, c = W2 + lane + kWave * cc;
-          tmp[rr * NC + cc] = (c <= row2) ? pr * T[size_t(row2) * D + c] : 0.0;
-        }
-      // beyond the first 2d columns L is lower triangular like L^-: the zeros above the diagonal are structural (every
-      // kernel that writes a state factor leaves exact zeros there, the slots are zero-initialised), so only c <= row
-      // is written
-#pragma unroll
-      for (int rr = 0; rr < 16; ++rr)
-#pragma unroll
-        for (int cc = 0; cc < NC; ++cc) {
-          const int row2 = 16 * st + rr, c = W2 + lane + kWave * cc;
-          if (c <= row2) Ln[size_t(row2) * D + c] = tmp[rr * NC + cc];
-        }
-    }
+    // (columns >= 2d of these rows were written by the LQ kernel, already scaled)
     lap(4);
   }
   if (stamp && lane == 0) {
