@@ -315,14 +315,24 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
       constexpr int NL = 2 * kNB * D / 256;
       double tmp[NL];
       if constexpr (fused) {
+        // k outermost: the NL loads of one k are all in flight together (an e-outer loop exposes one memory latency
+        // per element and k)
 #pragma unroll
-        for (int e = 0; e < NL; ++e) {
-          const int idx = tid + 256 * e;
-          const int row = idx / D, cidx = idx % D;  // rows 0..31 lie in derivative block 0 or (d == 16) 0 and 1
-          const int ib = row / d, q = row % d;
-          double acc = 0.0;
-          for (int k = ib; k < nn; ++k) acc = fma(coef[ib * kMaxN + k], Lsrc[size_t(k * d + q) * D + cidx], acc);
-          tmp[e] = acc;
+        for (int e = 0; e < NL; ++e) tmp[e] = 0.0;
+        for (int k = 0; k < nn; ++k) {
+          double lv[NL];
+#pragma unroll
+          for (int e = 0; e < NL; ++e) {
+            const int idx = tid + 256 * e;
+            const int row = idx / D, cidx = idx % D;  // rows 0..31 lie in derivative block 0 or (d == 16) 0 and 1
+            const int ib = row / d, q = row % d;
+            lv[e] = (k >= ib) ? Lsrc[size_t(k * d + q) * D + cidx] : 0.0;
+          }
+#pragma unroll
+          for (int e = 0; e < NL; ++e) {
+            const int ib = ((tid + 256 * e) / D) / d;
+            tmp[e] = fma(coef[ib * kMaxN + k], lv[e], tmp[e]);  // coef is zero below the diagonal (k < ib)
+          }
         }
       } else
 #pragma unroll
