@@ -351,11 +351,25 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
     // ---- panel B rows <- reflectors of A (rows live in LDS; natural column order 16 tt + m)
     if (!(v.ablate & 4)) {
       const double4_t t0v = t0_tile(c0 + kNB, c0);
+      // G^T = V_A V_B^T: each wavefront contracts a quarter of the columns; the four partial tiles are summed in a
+      // fixed order (bit-reproducible) through LDS that is idle between the two panel factorisations
       double4_t ar0 = {0.0, 0.0, 0.0, 0.0}, ar1 = ar0;
+      constexpr int SQ = D / 16;  // k-steps (of 4 columns) per wavefront
 #pragma unroll 8
-      for (int s = 0; s < D / 4; s += 2) {
+      for (int s = SQ * wv; s < SQ * (wv + 1); s += 2) {
         ar0 = MFMA64(VA[r * LDV + 4 * s + g], VB[r * LDV + 4 * s + g], ar0);
         ar1 = MFMA64(VA[r * LDV + 4 * s + 4 + g], VB[r * LDV + 4 * s + 4 + g], ar1);
+      }
+      {
+        double* slot[4] = {Gm, Nm, psB.Tpp, psB.Tf};
+        const double4_t part = ar0 + ar1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) slot[wv][4 * lane + q] = part[q];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          ar0[q] = ((slot[0][4 * lane + q] + slot[1][4 * lane + q]) + slot[2][4 * lane + q]) + slot[3][4 * lane + q];
+        ar1 = {0.0, 0.0, 0.0, 0.0};
       }
       double4_t sc;
 #pragma unroll
