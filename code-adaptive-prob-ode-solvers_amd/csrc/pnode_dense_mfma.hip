@@ -691,9 +691,17 @@ __global__ __launch_bounds__(256) void dense_begin_mfma_kernel(DenseView v, cons
 template <int DT, int DD>
 __global__ __launch_bounds__(256, 2) void dense_gain_mfma_kernel(DenseView v, const StepArg* __restrict__ args,
                                                               const IwpConst* __restrict__ Kc) {
-  constexpr int D = 16 * DT, d = 16 * DD, W2 = 2 * d, LD = d + 1;
-  __shared__ double Sm[d * LD];
-  __shared__ double wz[d];
+  constexpr int D = 16 * DT, d = 16 * DD, W2 = 2 * d, LD = d + 1, LDF = W2 + 1;
+  // One LDS buffer, three lives: (1) J and T[0:d, 0:d] staged for the MFMA that forms F (both were MFMA operands read
+  // straight from global memory before: one exposed L2/HBM latency per k-step), (2) F itself, d x 2d, the operand of
+  // S = F F^T, (3) S and its Cholesky factor. F and W also go to global memory for the column solve and the strip kernel.
+  extern __shared__ double gbuf[];
+  double* Js = gbuf;            // [d][LD]      life 1
+  double* Ts = gbuf + d * LD;   // [d][LD]      life 1
+  double* Fl = gbuf;            // [d][LDF]     life 2
+  double* Sm = gbuf;            // [d][LD]      life 3
+  double* wz = gbuf + 2 * d * LD;      // [d]   (beyond all three)
+  double* invd = wz + d;               // [d]
   const int b = blockIdx.x;
   const StepArg arg = args[b];
   if (!arg.active) return;
@@ -706,40 +714,92 @@ __global__ __launch_bounds__(256, 2) void dense_gain_mfma_kernel(DenseView v, co
   const double* __restrict__ T = v.R + size_t(b) * D * D;
   const double* __restrict__ Jg = v.J + size_t(b) * d * d;
   double* __restrict__ F = v.Ft + size_t(b) * d * D;  // [d][W2] used
-  // F[:, d:2d] = p1 T[d:2d, d:2d] (lower triangular block)
+  // ---- life 1: stage J and the lower-triangular T[0:d, 0:d] (coalesced), form F[:, 0:d] = p1 T[d:2d, 0:d] - p0 J T[0:d, 0:d]
   for (int idx = tid; idx < d * d; idx += 256) {
     const int a = idx / d, c = idx % d;
-    F[a * W2 + d + c] = (c <= a) ? p1 * T[size_t(d + a) * D + d + c] : 0.0;
-  }
-  // F[:, 0:d] = p1 T[d:2d, 0:d] - p0 J T[0:d, 0:d]   (MFMA, T[0:d,0:d] lower triangular)
-  for (int tile = wv; tile < DD * DD; tile += 4) {
-    const int ta = tile / DD, tc = tile % DD;
-    double4_t acc;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] = p1 * T[size_t(d + 16 * ta + g + 4 * q) * D + 16 * tc + r];
-#pragma unroll
-    for (int s = 0; s < d / 4; ++s) {  // T[0:d,0:d] is lower triangular: its upper part is stored as zeros
-      const int qq = 4 * s + g;
-      acc = MFMA64(-p0 * Jg[(16 * ta + r) * d + qq], T[size_t(qq) * D + 16 * tc + r], acc);
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) F[(16 * ta + g + 4 * q) * W2 + 16 * tc + r] = acc[q];
+    Js[a * LD + c] = -p0 * Jg[idx];
+    Ts[a * LD + c] = T[size_t(a) * D + c];  // (the upper part is stored as zeros)
   }
   for (int j = tid; j < d; j += 256) wz[j] = v.z[size_t(b) * d + j];
-  __syncthreads();
-  for (int tile = wv; tile < DD * DD; tile += 4) {
-    const int ta = tile / DD, tb = tile % DD;
-    if (tb > ta) continue;
-    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+  constexpr int NT = (DD * DD + 3) / 4;  // F1 tiles per wavefront
+  double4_t f1[NT];
 #pragma unroll
-    for (int s = 0; s < W2 / 4; ++s)
-      acc = MFMA64(F[(16 * ta + r) * W2 + 4 * s + g], F[(16 * tb + r) * W2 + 4 * s + g], acc);
+  for (int it = 0; it < NT; ++it) {
+    const int tile = wv + 4 * it;
+    if (tile < DD * DD) {
+      const int ta = tile / DD, tc = tile % DD;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) Sm[(16 * ta + g + 4 * q) * LD + 16 * tb + r] = acc[q];
+      for (int q = 0; q < 4; ++q) f1[it][q] = p1 * T[size_t(d + 16 * ta + g + 4 * q) * D + 16 * tc + r];
+    }
   }
   __syncthreads();
+#pragma unroll
+  for (int it = 0; it < NT; ++it) {
+    const int tile = wv + 4 * it;
+    if (tile < DD * DD) {
+      const int ta = tile / DD, tc = tile % DD;
+      double4_t acc = f1[it];
+#pragma unroll
+      for (int s = 0; s < d / 4; ++s) acc = MFMA64(Js[(16 * ta + r) * LD + 4 * s + g], Ts[(4 * s + g) * LD + 16 * tc + r], acc);
+      f1[it] = acc;
+    }
+  }
+  __syncthreads();  // everyone is done with J and T in LDS
+  // ---- life 2: F in LDS (and in global memory); F[:, d:2d] = p1 T[d:2d, d:2d] (lower triangular block)
+#pragma unroll
+  for (int it = 0; it < NT; ++it) {
+    const int tile = wv + 4 * it;
+    if (tile < DD * DD) {
+      const int ta = tile / DD, tc = tile % DD;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        Fl[(16 * ta + g + 4 * q) * LDF + 16 * tc + r] = f1[it][q];
+        F[(16 * ta + g + 4 * q) * W2 + 16 * tc + r] = f1[it][q];
+      }
+    }
+  }
+  for (int idx = tid; idx < d * d; idx += 256) {
+    const int a = idx / d, c = idx % d;
+    const double val = (c <= a) ? p1 * T[size_t(d + a) * D + d + c] : 0.0;
+    Fl[a * LDF + d + c] = val;
+    F[a * W2 + d + c] = val;
+  }
+  __syncthreads();
+  constexpr int NLT = DD * (DD + 1) / 2, NS = (NLT + 3) / 4;  // lower tiles of S, and per wavefront
+  auto tile_of = [](int t, int& ta, int& tb) {  // t-th lower tile in row-major order
+    ta = 0;
+    while ((ta + 1) * (ta + 2) / 2 <= t) ++ta;
+    tb = t - ta * (ta + 1) / 2;
+  };
+  double4_t st[NS];
+#pragma unroll
+  for (int it = 0; it < NS; ++it) {
+    const int t = wv + 4 * it;
+    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+    if (t < NLT) {
+      int ta, tb;
+      tile_of(t, ta, tb);
+#pragma unroll 8
+      for (int s = 0; s < W2 / 4; ++s)
+        acc = MFMA64(Fl[(16 * ta + r) * LDF + 4 * s + g], Fl[(16 * tb + r) * LDF + 4 * s + g], acc);
+    }
+    st[it] = acc;
+  }
+  __syncthreads();  // everyone is done with F in LDS
+  // ---- life 3: S, Cholesky, substitution
+#pragma unroll
+  for (int it = 0; it < NS; ++it) {
+    const int t = wv + 4 * it;
+    if (t < NLT) {
+      int ta, tb;
+      tile_of(t, ta, tb);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Sm[(16 * ta + g + 4 * q) * LD + 16 * tb + r] = st[it][q];
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
   lds_cholesky_blocked<DD, LD>(Sm, tid);
-  __shared__ double invd[d];
   if (tid < d) invd[tid] = 1.0 / Sm[tid * LD + tid];
   __syncthreads();
   // one thread per column of F (and one for z): register-resident forward substitution
@@ -969,7 +1029,14 @@ static void launch_mfma(const DenseView& v, const StepArg* args, const IwpConst*
   mark(3);
   constexpr int d = 16 * DD, W2 = 2 * d;
   static_assert(DD <= 4, "the error norm is computed by strip block 0, which must cover the d rows of u");
-  hipLaunchKernelGGL((dense_gain_mfma_kernel<DT, DD>), dim3(v.B), dim3(256), 0, s, v, args, K);
+  const size_t shm1 = (size_t(2) * d * (d + 1) + 2 * d) * sizeof(double);  // >= d (2d + 1): see the kernel
+  static bool attr1 = false;
+  if (!attr1) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_gain_mfma_kernel<DT, DD>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, int(shm1));
+    attr1 = true;
+  }
+  hipLaunchKernelGGL((dense_gain_mfma_kernel<DT, DD>), dim3(v.B), dim3(256), shm1, s, v, args, K);
   const size_t shm2 = (size_t(d) * (W2 + 1) + W2 + 4) * sizeof(double);
   static bool attr2 = false;
   if (!attr2) {
