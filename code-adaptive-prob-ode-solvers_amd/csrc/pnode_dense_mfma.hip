@@ -1030,19 +1030,21 @@ static void launch_mfma(const DenseView& v, const StepArg* args, const IwpConst*
   constexpr int d = 16 * DD, W2 = 2 * d;
   static_assert(DD <= 4, "the error norm is computed by strip block 0, which must cover the d rows of u");
   const size_t shm1 = (size_t(2) * d * (d + 1) + 2 * d) * sizeof(double);  // >= d (2d + 1): see the kernel
-  static bool attr1 = false;
-  if (!attr1) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  static bool attr1[64] = {};  // the opt-in to > 64 KB of dynamic LDS is per function AND per device
+  if (!attr1[dev & 63]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_gain_mfma_kernel<DT, DD>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, int(shm1));
-    attr1 = true;
+    attr1[dev & 63] = true;
   }
   hipLaunchKernelGGL((dense_gain_mfma_kernel<DT, DD>), dim3(v.B), dim3(256), shm1, s, v, args, K);
   const size_t shm2 = (size_t(d) * (W2 + 1) + W2 + 4) * sizeof(double);
-  static bool attr2 = false;
-  if (!attr2) {
+  static bool attr2[64] = {};
+  if (!attr2[dev & 63]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_strip_update_mfma_kernel<DT, DD>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, int(shm2));
-    attr2 = true;
+    attr2[dev & 63] = true;
   }
   hipLaunchKernelGGL((dense_strip_update_mfma_kernel<DT, DD>), dim3(1, v.B), dim3(256), shm2, s, v, args, K);
   mark(4);
