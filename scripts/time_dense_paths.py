@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Step time of the dense kernels by path and size (Brusselator N, nu = 3): A/B tool behind the numbers in DESIGN.md §6.
 
-  python scripts/time_dense_paths.py N B PATH [filter|fixedpoint] [--phases]
+  python scripts/time_dense_paths.py N B PATH [filter|fixedpoint] [--phases] [--nu=3]
 
 PATH: 0 default dispatch, 1 generic kernels, 2 large-D kernels (pnode_set_generic_path).
 --phases prints the begin | LQ input | LQ | measurement-update split from HIP events (filter only).
@@ -59,4 +59,5 @@ def run(N, B, path, strategy="filter", phases=False, steps=4, nu=3):
 
 if __name__ == "__main__":
     a = [x for x in sys.argv[1:] if not x.startswith("--")]
-    run(int(a[0]), int(a[1]), int(a[2]), a[3] if len(a) > 3 else "filter", phases="--phases" in sys.argv)
+    nu = next((int(x.split("=")[1]) for x in sys.argv if x.startswith("--nu=")), 3)
+    run(int(a[0]), int(a[1]), int(a[2]), a[3] if len(a) > 3 else "filter", phases="--phases" in sys.argv, nu=nu)
