@@ -38,6 +38,8 @@ struct Gemm {
   const long* offC;    // optional per-trajectory element offsets of C (replaces b * sC)
   const long* offA;    // same for A
   const long* offB;    // same for B
+  int ksplit;          // > 1 (N <= 32 only): blockIdx.x selects a K-slice; slice kx writes its partial product to
+  long sPart;          //   C + kx * sPart (C0 is added by slice 0 only); sum_partials_kernel adds the slices up
 };
 
 // PD = register prefetch depth in k-tiles: the skinny shapes (N <= 32: a handful of workgroups per trajectory, K up to D)
@@ -53,7 +55,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(Gemm g) {
   __shared__ double Bs[TB ? BN * LDBS : KS * LDBS];
   const int b = blockIdx.z;
   if (g.act && !g.act[b]) return;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const bool split = g.ksplit > 1;
+  const int kx = split ? blockIdx.x : 0;
+  const int kbeg = split ? kx * (g.K / g.ksplit) : 0, kend = split ? kbeg + g.K / g.ksplit : g.K;
+  const int m0 = blockIdx.y * BM, n0 = split ? 0 : blockIdx.x * BN;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, gq = lane >> 4;
   const int wm = w / WNs, wn = w % WNs;
   const double* A = g.A + (g.offA ? g.offA[b] : long(b) * g.sA);
@@ -99,10 +104,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(Gemm g) {
       for (int q = 0; q < 4; ++q) Bs[nkr * LDBS + nc4 + q] = qb[q];
     }
   };
-  const int klast = g.K - KS;
+  const int klast = kend - KS;
 #pragma unroll
-  for (int u = 0; u < PD; ++u) fetch(u * KS < klast ? u * KS : klast, ra[u], rb[u]);
-  for (int kk0 = 0; kk0 < g.K; kk0 += PD * KS) {
+  for (int u = 0; u < PD; ++u) fetch(kbeg + u * KS < klast ? kbeg + u * KS : klast, ra[u], rb[u]);
+  for (int kk0 = kbeg; kk0 < kend; kk0 += PD * KS) {
 #pragma unroll
    for (int u = 0; u < PD; ++u) {
     const int kk = kk0 + u * KS;  // (the launcher guarantees K % (PD * KS) == 0)
@@ -126,8 +131,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(Gemm g) {
     __syncthreads();
    }
   }
-  const double* C0 = g.C0 ? g.C0 + long(b) * g.sC0 : nullptr;
-  double* C = g.C + (g.offC ? g.offC[b] : long(b) * g.sC);
+  const double* C0 = (g.C0 && kx == 0) ? g.C0 + long(b) * g.sC0 : nullptr;
+  double* C = g.C + (g.offC ? g.offC[b] : long(b) * g.sC) + long(kx) * g.sPart;
   // epilogue in two phases (all C0 loads in flight, then the stores): C0 may alias C element by element (in-place
   // updates), which would otherwise serialise every load behind the previous store
   double4_t c0v[2][2];
@@ -151,10 +156,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(Gemm g) {
       }
 }
 
+// P0 += P1 + ... (fixed order): the K-slices of a split skinny GEMM
+__global__ __launch_bounds__(256) void sum_partials_kernel(double* __restrict__ C, long sC, long sPart, int count, int nparts,
+                                                           const int32_t* __restrict__ act) {
+  const int b = blockIdx.y;
+  if (act && !act[b]) return;
+  double* c = C + long(b) * sC;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < count; e += gridDim.x * 256) {
+    double acc = c[e];
+    for (int k = 1; k < nparts; ++k) acc += c[e + long(k) * sPart];
+    c[e] = acc;
+  }
+}
+
 static void gemm(hipStream_t s, int batch, bool transB, const Gemm& g) {
   if (g.M <= 0 || g.N <= 0 || batch <= 0) return;
   if (g.N <= 32) {
-    dim3 grid((g.N + 31) / 32, (g.M + 127) / 128, batch);
+    dim3 grid(g.ksplit > 1 ? g.ksplit : (g.N + 31) / 32, (g.M + 127) / 128, batch);
     if (transB && g.K % 64 == 0)
       hipLaunchKernelGGL((gemm_kernel<true, 4, 1, 4>), grid, dim3(256), 0, s, g);
     else if (transB)
@@ -830,7 +848,13 @@ static void blocked_lq(const DenseView& v, int rows_total, hipStream_t s) {
       double* Vp = v.M + size_t(p0) * D;       // scaled reflector rows (32 x D)
       double* Tb = v.R + size_t(j0) * D + p0;  // trailing rows of T, panel columns
       Gemm g1{Mb, Vp, Tb, v.lgG, sDD, sDD, sDD, sG, D, D, D, PB, rows, PB, D, 1.0, 1.0, v.act, nullptr};
+      // one workgroup per trajectory would walk all of K alone (latency-bound, a quarter of the CUs busy): K-slices of 256
+      g1.ksplit = D / 256 > 1 ? D / 256 : 1;
+      g1.sPart = long(rows) * PB;
       gemm(s, B, true, g1);  // G = T[:, panel] + Mt V^T
+      if (g1.ksplit > 1)
+        hipLaunchKernelGGL(sum_partials_kernel, dim3((rows * PB + 255) / 256, B), dim3(256), 0, s, v.lgG, sG, g1.sPart, rows * PB,
+                           g1.ksplit, v.act);
       Gemm g2{v.lgG, Tf, nullptr, v.lgW, sG, long(tfs), 0, sG, PB, PB, 0, PB, rows, PB, PB, 1.0, 0.0, v.act, nullptr};
       gemm(s, B, false, g2);  // W = G Tf
       Gemm g3{v.lgG, Tf, Tb, Tb, sG, long(tfs), sDD, sDD, PB, PB, D, D, rows, PB, PB, -1.0, 1.0, v.act, nullptr};
