@@ -524,18 +524,21 @@ __device__ void forward_vec(const double* C, int d, double* x) {
 // begin, part 1: activity flags, m^-, f, J, z, and F1 = [B_0 .. B_k] (d x (k+1)d, leading dimension D, into v.X) with
 // B_j = lq[k][j] I - sum_{i<k} lq[i][j] J_i, so that S1 = F1 F1^T; diag(S1) -> v.err
 __global__ __launch_bounds__(256) void begin_a_kernel(DenseView v, const StepArg* __restrict__ args, const IwpConst* __restrict__ Kc) {
+  // grid (G, B): every workgroup of a trajectory extrapolates the (small) mean redundantly; the rows of J, F1 and
+  // diag(S1) are split over the G workgroups; workgroup 0 owns the per-trajectory outputs (flags, m^-, z)
   extern __shared__ double smem[];
-  const int b = blockIdx.x;
+  const int b = blockIdx.y;
+  const bool first = blockIdx.x == 0;
   const StepArg arg = args[b];
-  if (threadIdx.x == 0) {
+  if (first && threadIdx.x == 0) {
     v.act[b] = arg.active ? 1 : 0;
     v.lgOff[b] = (long(arg.dst) * v.B + b) * long(v.D) * v.D;
   }
   if (!arg.active) return;
   const IwpConst& K = *Kc;
   const int d = v.d, k = v.k, n = v.n, kd = k * d, D = v.D;
-  double* ybuf = smem;     // [k][d]
-  double* lq = ybuf + kd;  // [n][n]
+  double* ybuf = smem;      // [k+1][d]  (row k: the derivative the residual is taken against)
+  double* lq = ybuf + kd + d;  // [n][n]
   double p[kMaxN], pinv[kMaxN];
   precond(n, arg.dt, K, p, pinv);
   for (int idx = threadIdx.x; idx < n * n; idx += 256) {
@@ -550,34 +553,44 @@ __global__ __launch_bounds__(256) void begin_a_kernel(DenseView v, const StepArg
       double acc = 0.0;
       for (int kk = i; kk < n; ++kk) acc += K.a[i][kk] * pinv[kk] * msrc[kk * d + j];
       const double e = p[i] * acc;
-      mdst[i * d + j] = e;
-      if (v.fixedpoint) v.mext[size_t(b) * n * d + i * d + j] = e;
-      if (i < k) ybuf[i * d + j] = e;
+      if (first) {
+        mdst[i * d + j] = e;
+        if (v.fixedpoint) v.mext[size_t(b) * n * d + i * d + j] = e;
+      }
+      if (i <= k) ybuf[i * d + j] = e;
     }
   __syncthreads();
   VfCtx ctx{v.vf_id, d, k, v.prm ? v.prm + (v.prm_per_traj ? size_t(b) * v.P : 0) : nullptr,
             v.user_f ? v.user_f + size_t(b) * d : nullptr, v.user_J ? v.user_J + size_t(b) * d * k * d : nullptr};
   const double tnew = arg.t + arg.dt;
-  for (int j = threadIdx.x; j < d; j += 256) v.z[size_t(b) * d + j] = mdst[k * d + j] - vf_f(ctx, ybuf, j, tnew);
+  if (first)
+    for (int j = threadIdx.x; j < d; j += 256) v.z[size_t(b) * d + j] = ybuf[k * d + j] - vf_f(ctx, ybuf, j, tnew);
+  const int G = gridDim.x, rows_per = (d + G - 1) / G;
+  const int a0 = blockIdx.x * rows_per, a1 = (a0 + rows_per < d) ? a0 + rows_per : d;
   double* Jg = v.J + size_t(b) * d * kd;
-  for (int idx = threadIdx.x; idx < d * kd; idx += 256) {
+  for (int idx = a0 * kd + threadIdx.x; idx < a1 * kd; idx += 256) {
     const int a = idx / kd, rest = idx % kd;
     Jg[idx] = vf_jac(ctx, ybuf, a, rest / d, rest % d, tnew);
   }
   __syncthreads();
   double* F1 = v.X + size_t(b) * d * D;
-  for (int idx = threadIdx.x; idx < d * (k + 1) * d; idx += 256) {
-    const int a = idx / ((k + 1) * d), rest = idx % ((k + 1) * d);
+  const int w1 = (k + 1) * d;
+  for (int idx = a0 * w1 + threadIdx.x; idx < a1 * w1; idx += 256) {
+    const int a = idx / w1, rest = idx % w1;
     const int j = rest / d, c = rest % d;
     double val = (a == c) ? lq[k * n + j] : 0.0;
     for (int i = 0; i < k; ++i) val -= lq[i * n + j] * Jg[a * kd + i * d + c];
     F1[size_t(a) * D + rest] = val;
   }
   __syncthreads();
-  for (int a = threadIdx.x; a < d; a += 256) {
-    double acc = 0.0;
-    for (int c = 0; c < (k + 1) * d; ++c) acc = fma(F1[size_t(a) * D + c], F1[size_t(a) * D + c], acc);
-    v.err[size_t(b) * d + a] = acc;
+  {  // diag(S1) = squared row norms of F1: one wavefront per row (coalesced)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int a = a0 + wv; a < a1; a += 4) {
+      double acc = 0.0;
+      for (int c = lane; c < w1; c += kWave) acc = fma(F1[size_t(a) * D + c], F1[size_t(a) * D + c], acc);
+      acc = wave_sum(acc);
+      if (lane == 0) v.err[size_t(b) * d + a] = acc;
+    }
   }
 }
 
@@ -936,8 +949,8 @@ void dense_large_launch_step(const DenseView& v, const StepArg* args, const IwpC
   const int B = v.B, d = v.d, k = v.k, D = v.D, kd = k * d;
   const long sDD = long(v.mr_rows) * D * D;
   // ---- begin
-  const size_t shm_a = (size_t(kd) + size_t(v.n) * v.n) * sizeof(double);
-  hipLaunchKernelGGL(begin_a_kernel, dim3(B), dim3(256), shm_a, s, v, args, K);
+  const size_t shm_a = (size_t(kd) + d + size_t(v.n) * v.n) * sizeof(double);
+  hipLaunchKernelGGL(begin_a_kernel, dim3(d >= 128 ? 8 : 2, B), dim3(256), shm_a, s, v, args, K);
   {
     Gemm g{v.X, v.X, nullptr, v.S, long(d) * D, long(d) * D, 0, long(d) * d, D, D, 0, d, d, d, (k + 1) * d, 1.0, 0.0, v.act, nullptr};
     gemm(s, B, true, g);
