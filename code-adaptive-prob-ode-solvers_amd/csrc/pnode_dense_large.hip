@@ -509,14 +509,36 @@ __device__ __forceinline__ double block_sum256(double val, double* red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
-// x <- C^-1 x (lower C, d x d, global), whole workgroup
+// x <- C^-1 x (lower C, d x d, global; d % 32 == 0), whole workgroup (256 threads). Blocked by 32: wavefront 0 solves
+// the diagonal block in registers (lane = row, pivots broadcast with v_readlane: no barriers), then every thread
+// subtracts the block's contribution from one of the rows below. Two barriers per 32 rows instead of two per row.
 __device__ void forward_vec(const double* C, int d, double* x) {
-  for (int a = 0; a < d; ++a) {
+  __shared__ double xs[PB];
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int a0 = 0; a0 < d; a0 += PB) {
     __syncthreads();
-    const double xa = x[a] / C[size_t(a) * d + a];
+    if (tid < 64) {
+      double xr = (lane < PB) ? x[a0 + lane] : 0.0;
+      for (int a = 0; a < PB; ++a) {
+        const double piv = C[size_t(a0 + a) * d + a0 + a];
+        const int lo = __builtin_amdgcn_readlane(__double2loint(xr), a), hi = __builtin_amdgcn_readlane(__double2hiint(xr), a);
+        const double xa = __hiloint2double(hi, lo) / piv;
+        if (lane == a) xr = xa;
+        else if (lane > a && lane < PB) xr = fma(-C[size_t(a0 + lane) * d + a0 + a], xa, xr);
+      }
+      if (lane < PB) {
+        x[a0 + lane] = xr;
+        xs[lane] = xr;
+      }
+    }
     __syncthreads();
-    if (threadIdx.x == 0) x[a] = xa;
-    for (int r = a + 1 + threadIdx.x; r < d; r += 256) x[r] -= C[size_t(r) * d + a] * xa;
+    for (int r = a0 + PB + tid; r < d; r += 256) {
+      const double* cr = C + size_t(r) * d + a0;
+      double acc = x[r];
+#pragma unroll 8
+      for (int a = 0; a < PB; ++a) acc = fma(-cr[a], xs[a], acc);
+      x[r] = acc;
+    }
   }
   __syncthreads();
 }
