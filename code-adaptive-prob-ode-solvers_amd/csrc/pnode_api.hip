@@ -178,6 +178,16 @@ int pnode_destroy(pnode_batch* h) {
     if (ptr) h->allocations.push_back((void*)(ptr));      \
   } while (0)
 
+// After `new pnode_batch`: every failure releases the handle (stream, events, pinned and device memory) before returning.
+#define HIP_TRY_H(expr)                                                                         \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess) {                                                                     \
+      pnode_destroy(h);                                                                         \
+      return fail(PNODE_EDEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));            \
+    }                                                                                           \
+  } while (0)
+
 int pnode_create(const pnode_config* cfg, pnode_batch** out) {
   if (!cfg || !out) return fail(PNODE_EINVAL, "null argument");
   *out = nullptr;
@@ -223,20 +233,20 @@ int pnode_create(const pnode_config* cfg, pnode_batch** out) {
   h->D = h->n * d;
   h->dense = cfg->model == PNODE_MODEL_DENSE;
   const size_t B = cfg->batch, n = h->n, D = h->D, Kc = cfg->num_checkpoints;
-  HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-  HIP_TRY(hipEventCreate(&h->ev0));
-  HIP_TRY(hipEventCreate(&h->ev1));
-  for (auto& e : h->phase.ev) HIP_TRY(hipEventCreate(&e));
-  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->hArgs), B * sizeof(StepArg)));
-  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->hIargs), B * sizeof(InterpArg)));
-  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->hErr), B * sizeof(double)));
-  HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->zArgs), h->hArgs, 0));
-  HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->zErr), h->hErr, 0));
-  HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->zIargs), h->hIargs, 0));
-  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->hFp0), B * sizeof(FpArg)));
-  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->hFp1), B * sizeof(FpArg)));
-  HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->zFp0), h->hFp0, 0));
-  HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->zFp1), h->hFp1, 0));
+  HIP_TRY_H(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  HIP_TRY_H(hipEventCreate(&h->ev0));
+  HIP_TRY_H(hipEventCreate(&h->ev1));
+  for (auto& e : h->phase.ev) HIP_TRY_H(hipEventCreate(&e));
+  HIP_TRY_H(hipHostMalloc(reinterpret_cast<void**>(&h->hArgs), B * sizeof(StepArg)));
+  HIP_TRY_H(hipHostMalloc(reinterpret_cast<void**>(&h->hIargs), B * sizeof(InterpArg)));
+  HIP_TRY_H(hipHostMalloc(reinterpret_cast<void**>(&h->hErr), B * sizeof(double)));
+  HIP_TRY_H(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->zArgs), h->hArgs, 0));
+  HIP_TRY_H(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->zErr), h->hErr, 0));
+  HIP_TRY_H(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->zIargs), h->hIargs, 0));
+  HIP_TRY_H(hipHostMalloc(reinterpret_cast<void**>(&h->hFp0), B * sizeof(FpArg)));
+  HIP_TRY_H(hipHostMalloc(reinterpret_cast<void**>(&h->hFp1), B * sizeof(FpArg)));
+  HIP_TRY_H(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->zFp0), h->hFp0, 0));
+  HIP_TRY_H(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->zFp1), h->hFp1, 0));
 
   ALLOC(h->dK, 1);
   ALLOC(h->dArgs, B);
@@ -247,7 +257,7 @@ int pnode_create(const pnode_config* cfg, pnode_batch** out) {
   ALLOC(h->dErr, B);
   const size_t nprm = size_t(cfg->num_vf_params) * (cfg->vf_params_per_trajectory ? B : 1);
   ALLOC(h->dPrm, nprm);
-  if (nprm) HIP_TRY(hipMemcpy(h->dPrm, cfg->vf_params, nprm * sizeof(double), hipMemcpyHostToDevice));
+  if (nprm) HIP_TRY_H(hipMemcpy(h->dPrm, cfg->vf_params, nprm * sizeof(double), hipMemcpyHostToDevice));
   if (cfg->vf_id == PNODE_VF_USER) {
     ALLOC(h->dUserF, B * size_t(d));
     ALLOC(h->dUserJ, B * size_t(d) * k * d);
@@ -255,7 +265,7 @@ int pnode_create(const pnode_config* cfg, pnode_batch** out) {
   }
   IwpConst hk;
   fill_iwp(cfg->nu, &hk);
-  HIP_TRY(hipMemcpy(h->dK, &hk, sizeof(hk), hipMemcpyHostToDevice));
+  HIP_TRY_H(hipMemcpy(h->dK, &hk, sizeof(hk), hipMemcpyHostToDevice));
 
   if (!h->dense) {
     IsoView& v = h->iso;
@@ -283,7 +293,6 @@ int pnode_create(const pnode_config* cfg, pnode_batch** out) {
     DenseView& v = h->dn;
     v.B = int(B); v.d = d; v.k = k; v.n = int(n); v.D = int(D); v.K = int(Kc);
     v.ts1 = cfg->correction == PNODE_CORR_TS1;
-    v.ablate = getenv("PNODE_ABLATE") ? atoi(getenv("PNODE_ABLATE")) : 0;
     v.dynamic = cfg->calibration == PNODE_CALIB_DYNAMIC;
     v.vf_id = cfg->vf_id; v.P = cfg->num_vf_params; v.prm_per_traj = cfg->vf_params_per_trajectory;
     v.fixedpoint = cfg->strategy == PNODE_STRATEGY_FIXEDPOINT;
@@ -335,12 +344,6 @@ int pnode_create(const pnode_config* cfg, pnode_batch** out) {
     }
     v.atol = h->dAtol; v.rtol = h->dRtol; v.prm = nprm ? h->dPrm : nullptr; v.errnorm = h->zErr;
     v.user_f = h->dUserF; v.user_J = h->dUserJ;
-    // A/B testing through the high-level API: PNODE_DENSE_PATH=1 (generic kernels) / 2 (large-D path where supported)
-    if (const char* pth = getenv("PNODE_DENSE_PATH")) {
-      const int e = atoi(pth);
-      if (e == 1) { v.force_generic = 1; v.user_generic = 1; }
-      if (e == 2 && dense_large_supported(v)) v.force_large = 1;
-    }
   }
   h->t_sf.assign(B, 0.0);
   h->t_if.assign(B, 0.0);
@@ -352,8 +355,8 @@ int pnode_create(const pnode_config* cfg, pnode_batch** out) {
   h->pending.assign(B, 0);
   // default tolerances (ivpsolve.adaptive defaults: atol 1e-4, rtol 1e-2)
   std::vector<double> a(B, 1e-4), r(B, 1e-2);
-  HIP_TRY(hipMemcpy(h->dAtol, a.data(), B * sizeof(double), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(h->dRtol, r.data(), B * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY_H(hipMemcpy(h->dAtol, a.data(), B * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY_H(hipMemcpy(h->dRtol, r.data(), B * sizeof(double), hipMemcpyHostToDevice));
   *out = h;
   return PNODE_OK;
 }
@@ -846,14 +849,15 @@ int pnode_solve_fixed_grid(pnode_batch* h, const double* grid, int32_t G, int32_
   e = hipMemcpyAsync(dAll, all.data(), all.size() * sizeof(StepArg), hipMemcpyHostToDevice, h->stream);
   if (e != hipSuccess) { cleanup(); return fail(PNODE_EDEVICE, hipGetErrorString(e)); }
   double* mean = mean_base(h);
-  HIP_TRY(hipEventRecord(h->ev0, h->stream));
+  e = hipEventRecord(h->ev0, h->stream);
+  if (e != hipSuccess) { cleanup(); return fail(PNODE_EDEVICE, hipGetErrorString(e)); }
   for (int g = 0; g < G; ++g) {
     if (g > 0) enqueue_step(h, dAll + size_t(g) * B);
     hipLaunchKernelGGL(gather_u_kernel, dim3(unsigned(B)), dim3(64), 0, h->stream, mean, dAll + size_t(g) * B, dU, int(B),
                        int(n), int(d), G, g);
   }
-  HIP_TRY(hipEventRecord(h->ev1, h->stream));
-  e = hipMemcpyAsync(u_out, dU, B * size_t(G) * d * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+  e = hipEventRecord(h->ev1, h->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(u_out, dU, B * size_t(G) * d * sizeof(double), hipMemcpyDeviceToHost, h->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
   if (e == hipSuccess) e = hipGetLastError();
   cleanup();
@@ -975,15 +979,6 @@ int pnode_set_generic_path(pnode_batch* h, int32_t enabled) {
   h->dn.force_generic = enabled == 1 || h->dn.fixedpoint;  // the register-resident MFMA kernels have no extra-row LQ
   h->dn.user_generic = enabled == 1;
   h->dn.force_large = enabled == 2;
-  return PNODE_OK;
-}
-
-// Diagnostics: copy `count` 64-bit words of the X scratch of trajectory b (after the tv head) to the host.
-int pnode_debug_read_scratch(pnode_batch* h, int32_t b, int32_t offset_words, int32_t count, uint64_t* out) {
-  if (!h || !out || !h->dense) return fail(PNODE_EINVAL, "bad argument");
-  const size_t D = h->D, d = h->cfg.d;
-  HIP_TRY(hipMemcpy(out, reinterpret_cast<uint64_t*>(h->dn.X + size_t(b) * D * d) + offset_words, size_t(count) * 8,
-                    hipMemcpyDeviceToHost));
   return PNODE_OK;
 }
 

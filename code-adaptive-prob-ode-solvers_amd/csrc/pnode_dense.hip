@@ -383,7 +383,7 @@ void dense_launch_step(const DenseView& v, const StepArg* args, const IwpConst* 
     return;
   }
   const size_t shm_begin = (size_t(v.k) * v.d + v.d + 4 + size_t(v.n) * v.n) * sizeof(double);
-  if (fast && v.ts1 && !(v.ablate & 32))
+  if (fast && v.ts1)
     dense_launch_mfma_begin(v, args, K, s);
   else
     hipLaunchKernelGGL(dense_begin_kernel, dim3(v.B), dim3(kThreads), shm_begin, s, v, args, K);

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(Gemm g) {
   for (int kk0 = kbeg; kk0 < kend; kk0 += PD * KS) {
 #pragma unroll
    for (int u = 0; u < PD; ++u) {
-    const int kk = kk0 + u * KS;  // (the launcher guarantees K % (PD * KS) == 0)
+    const int kk = kk0 + u * KS;  // (the launcher guarantees that K and every K-slice are multiples of PD * KS)
     stash(ra[u], rb[u]);
     __syncthreads();
     fetch(kk + PD * KS < klast ? kk + PD * KS : klast, ra[u], rb[u]);  // (past the end: a harmless re-read of the last tile)
@@ -884,7 +884,18 @@ static void blocked_lq(const DenseView& v, int rows_total, hipStream_t s) {
       double* Tb = v.R + size_t(j0) * D + p0;  // trailing rows of T, panel columns
       Gemm g1{Mb, Vp, Tb, v.lgG, sDD, sDD, sDD, sG, D, D, D, PB, rows, PB, D, 1.0, 1.0, v.act, nullptr};
       // one workgroup per trajectory would walk all of K alone (latency-bound, a quarter of the CUs busy): K-slices of 256
-      g1.ksplit = D / 256 > 1 ? D / 256 : 1;
+      // A slice must be a whole number of PD * KS = 64-wide k-steps (D = 576, 704, 832, 896 ... would otherwise
+      // accumulate a clamped tail tile more than once or drop columns): among 2, 3, 4 slices take the one whose
+      // slice length is closest to 256, none if D / 64 has no such divisor.
+      g1.ksplit = 1;
+      if (D >= 512) {
+        int best = 1 << 30;
+        for (int ks = 2; ks <= 4; ++ks)
+          if (D % (64 * ks) == 0 && abs(D / ks - 256) < best) {
+            best = abs(D / ks - 256);
+            g1.ksplit = ks;
+          }
+      }
       g1.sPart = long(rows) * PB;
       gemm(s, B, true, g1);  // G = T[:, panel] + Mt V^T
       if (g1.ksplit > 1)

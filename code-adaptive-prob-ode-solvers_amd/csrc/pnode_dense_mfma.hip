@@ -80,7 +80,7 @@ struct PanelScratch {
 // and ps.Tf the compact-WY factor.
 template <int DT, int LDV>
 __device__ __forceinline__ void factor_panel(double* rows, const PanelScratch& ps, double* Gm, double* Nm, double t0diag,
-                                             int tid, int ablate) {
+                                             int tid) {
   const int rr = tid >> 4, ch = tid & 15;
   // the sweep is a chain of dependent short instructions: give it issue priority over the co-resident
   // workgroup's MFMA stream (which only needs one issue slot per 64 cycles)
@@ -121,7 +121,7 @@ __device__ __forceinline__ void factor_panel(double* rows, const PanelScratch& p
   };
   if (rr == 0) publish_scalars(0);
   __syncthreads();
-  for (int c = 0; c < ((ablate & 1) ? 0 : kNB); ++c) {
+  for (int c = 0; c < kNB; ++c) {
     double xc[DT];
     double d0 = 0.0, d1 = 0.0;
 #pragma unroll
@@ -286,16 +286,6 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
     return t;
   };
 
-  const bool stamp = (v.ablate & 128) != 0;
-  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long tprev = stamp ? __builtin_amdgcn_s_memtime() : 0ull;
-  auto lap = [&](int slot) {
-    if (stamp) {
-      const unsigned long long now = __builtin_amdgcn_s_memtime();
-      tacc[slot] += now - tprev;
-      tprev = now;
-    }
-  };
   // Columns >= 2d of L^- are not touched by the measurement update (F = H L^- has 2d non-zero columns): the passes
   // that produce them write p_row * T straight into the destination slot of the state factor, so the strip-update
   // kernel neither reads nor copies them.
@@ -344,12 +334,10 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
       }
     }
     __syncthreads();
-    lap(0);
     // ---- panel A
-    factor_panel<DT, LDV>(VA, psA, Gm, Nm, sigma * K.qsT[c0 / d][c0 / d], tid, v.ablate);
-    lap(1);
+    factor_panel<DT, LDV>(VA, psA, Gm, Nm, sigma * K.qsT[c0 / d][c0 / d], tid);
     // ---- panel B rows <- reflectors of A (rows live in LDS; natural column order 16 tt + m)
-    if (!(v.ablate & 4)) {
+    {
       const double4_t t0v = t0_tile(c0 + kNB, c0);
       // G^T = V_A V_B^T: each wavefront contracts a quarter of the columns; the four partial tiles are summed in a
       // fixed order (bit-reproducible) through LDS that is idle between the two panel factorisations
@@ -399,10 +387,8 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
       }
       __syncthreads();
     }
-    lap(2);
     // ---- panel B
-    factor_panel<DT, LDV>(VB, psB, Gm, Nm, sigma * K.qsT[(c0 + kNB) / d][(c0 + kNB) / d], tid, v.ablate);
-    lap(3);
+    factor_panel<DT, LDV>(VB, psB, Gm, Nm, sigma * K.qsT[(c0 + kNB) / d][(c0 + kNB) / d], tid);
     // ---- diagonal blocks of T
     {
       const int i = tid >> 4, j = tid & 15;
@@ -417,9 +403,8 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
         }
       }
     }
-    lap(4);
     // ---- trailing strips: both panels in one pass over the rows
-    const int nstrips = (v.ablate & 2) ? 0 : DT - 2 * (P + 1);
+    const int nstrips = DT - 2 * (P + 1);
     auto load_strip = [&](int st, double (&X)[4 * DT]) {
       const int j0 = c0 + 2 * kNB + kNB * st;
       const double* __restrict__ rowp = Mt + size_t(j0 + r) * D + 16 * g;
@@ -484,7 +469,6 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
       apply_both(st, X);
       if (!(keeper && last)) store_strip(st, X);
     }
-    lap(5);
     __syncthreads();  // every wavefront is done with the reflectors in Vx
     if (keeper) {
 #pragma unroll
@@ -493,11 +477,6 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
         for (int e = 0; e < 16; ++e) Vx[(kNB * wv + r) * LDV + 64 * T4 + 16 * g + e] = X[16 * T4 + e];
     }
     carried = carry;  // (the barrier at the top of the next pass publishes the rows)
-    lap(6);
-  }
-  if (stamp && lane == 0) {
-    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(v.X + size_t(b) * D * d) + 512 + wv * 8;
-    for (int i = 0; i < 8; ++i) dbg[i] = tacc[i];
   }
 }
 
@@ -855,16 +834,6 @@ __global__ __launch_bounds__(256, 2) void dense_strip_update_mfma_kernel(DenseVi
   const int r = lane & 15, g = lane >> 4;
   const double* __restrict__ T = v.R + size_t(b) * D * D;
   const double* __restrict__ Wg = v.Ft + size_t(b) * d * D;
-  const bool stamp = (v.ablate & 128) != 0;
-  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long tprev = stamp ? __builtin_amdgcn_s_memtime() : 0ull;
-  auto lap = [&](int slot) {
-    if (stamp) {
-      const unsigned long long now = __builtin_amdgcn_s_memtime();
-      tacc[slot] += now - tprev;
-      tprev = now;
-    }
-  };
   {
     constexpr int NL = d * W2 / 512;  // double2 loads per thread
     double2 tmp[NL];
@@ -879,7 +848,6 @@ __global__ __launch_bounds__(256, 2) void dense_strip_update_mfma_kernel(DenseVi
   }
   for (int c = tid; c < W2; c += 256) tv[c] = v.X[size_t(b) * D * d + c];
   __syncthreads();
-  lap(0);
   const size_t sB = size_t(v.B);
   double* mdst = v.mean + (size_t(arg.dst) * sB + b) * D;
   double* __restrict__ Ln = v.U + (size_t(arg.dst) * sB + b) * D * D;
@@ -915,7 +883,6 @@ __global__ __launch_bounds__(256, 2) void dense_strip_update_mfma_kernel(DenseVi
     mpart += __shfl_xor(mpart, 16, kWave);
     mpart += __shfl_xor(mpart, 32, kWave);
     if (g == 0) mdst[row] -= mpart;
-    lap(1);
     double4_t yT[DD];
 #pragma unroll
     for (int ta = 0; ta < DD; ++ta) {
@@ -960,11 +927,6 @@ __global__ __launch_bounds__(256, 2) void dense_strip_update_mfma_kernel(DenseVi
         }
     }
     // (columns >= 2d of these rows were written by the LQ kernel, already scaled)
-    lap(4);
-  }
-  if (stamp && lane == 0) {
-    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(v.X + size_t(b) * D * d) + 1024 + wv * 8;
-    for (int i = 0; i < 8; ++i) dbg[i] = tacc[i];
   }
   {
     // error norm over u = m[0] (rows 0 .. d-1 were updated above)
@@ -985,28 +947,6 @@ __global__ __launch_bounds__(256, 2) void dense_strip_update_mfma_kernel(DenseVi
   }
 }
 
-// Mt = (Abar P^-1 (x) I) L  only (T0 is generated inside the LQ kernel).
-__global__ __launch_bounds__(256) void dense_mt_kernel(DenseView v, const StepArg* __restrict__ args,
-                                                       const IwpConst* __restrict__ Kc) {
-  const int b = blockIdx.y;
-  const StepArg arg = args[b];
-  if (!arg.active) return;
-  const IwpConst& K = *Kc;
-  const int d = v.d, n = v.n, D = v.D;
-  double p[kMaxN], pinv[kMaxN];
-  precond_rt(n, arg.dt, K, p, pinv);
-  const double* __restrict__ L = v.U + (size_t(arg.src) * v.B + b) * D * D;
-  double* __restrict__ Mt = v.M + size_t(b) * D * D;
-  for (int row = blockIdx.x; row < D; row += gridDim.x) {
-    const int i = row / d, q = row % d;
-    for (int c = threadIdx.x; c < D; c += 256) {
-      double acc = 0.0;
-      for (int kk = i; kk < n; ++kk) acc += K.a[i][kk] * pinv[kk] * L[size_t(kk * d + q) * D + c];
-      Mt[size_t(row) * D + c] = acc;
-    }
-  }
-}
-
 bool dense_mfma_supported(const DenseView& v) {
   if (v.k != 1 || v.d % 16 != 0) return false;
   const int DT = v.D / 16, DD = v.d / 16;
@@ -1018,14 +958,9 @@ static void launch_mfma(const DenseView& v, const StepArg* args, const IwpConst*
   auto mark = [&](int i) {
     if (ev) (void)hipEventRecord(ev->ev[i], s);
   };
-  if (v.ablate & 1024) hipLaunchKernelGGL(dense_mt_kernel, dim3(64, v.B), dim3(256), 0, s, v, args, K);
   mark(2);
-  if (v.ablate & 1024) {  // A/B: separate Mt kernel + all passes from Mt
-    hipLaunchKernelGGL((dense_lq2_mfma_kernel<DT, false>), dim3(v.B), dim3(256), 0, s, v, args, K, 0);
-  } else {
-    hipLaunchKernelGGL((dense_lq2_mfma_kernel<DT, true>), dim3(v.B), dim3(256), 0, s, v, args, K, 0);
-    hipLaunchKernelGGL((dense_lq2_mfma_kernel<DT, false>), dim3(v.B), dim3(256), 0, s, v, args, K, 1);
-  }
+  hipLaunchKernelGGL((dense_lq2_mfma_kernel<DT, true>), dim3(v.B), dim3(256), 0, s, v, args, K, 0);
+  hipLaunchKernelGGL((dense_lq2_mfma_kernel<DT, false>), dim3(v.B), dim3(256), 0, s, v, args, K, 1);
   mark(3);
   constexpr int d = 16 * DD, W2 = 2 * d;
   static_assert(DD <= 4, "the error norm is computed by strip block 0, which must cover the d rows of u");

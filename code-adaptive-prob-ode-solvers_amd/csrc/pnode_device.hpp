@@ -38,7 +38,6 @@ struct DenseView {
   int B, d, k, n, D, K;
   int ts1, dynamic, vf_id, P, prm_per_traj;
   int force_generic;  // 1: never take the MFMA fast path (A/B testing)
-  int ablate;         // timing-only diagnostics (PNODE_ABLATE env): results are WRONG when non-zero
   double* mean;   // [3][B][n][d]
   double* U;      // [3][B][D][D]   Sigma = U^T U (row-major)
   double* sigma;  // [3][B]

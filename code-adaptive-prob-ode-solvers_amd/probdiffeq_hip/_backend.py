@@ -62,6 +62,11 @@ class PnodeConfig(C.Structure):
 
 _lib = None
 
+# A/B testing of the dense device paths through the high-level API: every dense Batch created while this is non-zero
+# calls pnode_set_generic_path with it (1 = generic kernels, 2 = large-D kernels, 3 = previous two-launch LQ).
+# Tests set it with monkeypatch.setattr; nothing reads the environment.
+dense_path = 0
+
 
 def load_library():
     """Load libpnode_hip.so; raises OSError with a build hint if it is missing."""
@@ -170,10 +175,13 @@ class Batch:
         _check(lib.pnode_create(C.byref(cfg), C.byref(h)))
         self._h = h
         self.B, self.d, self.nu, self.n = batch, d, nu, nu + 1
+        self.ode_order = ode_order
         self.D = self.n * d
         self.K = num_checkpoints
         self.model, self.strategy = model, strategy
         self.device = device
+        if model == "dense" and dense_path:
+            self.set_generic_path(dense_path)
 
     def close(self):
         if self._h is not None:
@@ -196,16 +204,25 @@ class Batch:
         r = _f64(np.broadcast_to(rtol, (self.B,)))
         _check(self._lib.pnode_set_tolerances(self._h, _dp(a), _dp(r)))
 
+    def _flags(self, a, name):
+        a = np.ascontiguousarray(a, dtype=np.uint8)
+        if a.shape != (self.B,):
+            raise ValueError(f"{name} must have shape ({self.B},), got {a.shape}")
+        return a
+
     def attempt_step(self, dt, active, err_out):
         dt = _f64(dt, (self.B,))
-        active = np.ascontiguousarray(active, dtype=np.uint8)
+        active = self._flags(active, "active")
+        if not (isinstance(err_out, np.ndarray) and err_out.dtype == np.float64 and err_out.shape == (self.B,)
+                and err_out.flags.c_contiguous and err_out.flags.writeable):
+            raise ValueError(f"err_out must be a writeable C-contiguous float64 array of shape ({self.B},)")
         _check(self._lib.pnode_attempt_step(self._h, _dp(dt), active.ctypes.data_as(C.POINTER(C.c_uint8)), _dp(err_out)))
         return err_out
 
     def user_extrapolate(self, dt, active, ode_order):
         """PNODE_VF_USER: extrapolated means m^-[:ode_order] (B, k, d) at which the host evaluates the vector field."""
         y = np.zeros((self.B, ode_order, self.d))
-        active = np.ascontiguousarray(active, dtype=np.uint8)
+        active = self._flags(active, "active")
         _check(self._lib.pnode_user_extrapolate(self._h, _dp(_f64(dt, (self.B,))), active.ctypes.data_as(C.POINTER(C.c_uint8)), _dp(y)))
         return y
 
@@ -214,19 +231,27 @@ class Batch:
         jp = None
         if jac is not None:
             jac = _f64(jac)
+            if jac.size != self.B * self.d * self.ode_order * self.d:
+                raise ValueError(f"jac must have {self.B} x {self.d} x {self.ode_order * self.d} entries, got shape {jac.shape}")
             jp = _dp(jac)
         _check(self._lib.pnode_user_set_vf(self._h, _dp(f), jp))
 
     def commit(self, accept):
-        accept = np.ascontiguousarray(accept, dtype=np.uint8)
+        accept = self._flags(accept, "accept")
         _check(self._lib.pnode_commit(self._h, accept.ctypes.data_as(C.POINTER(C.c_uint8))))
 
-    def interpolate(self, t, slot):
+    def _slots(self, slot):
         slot = np.ascontiguousarray(slot, dtype=np.int32)
+        if slot.shape != (self.B,):
+            raise ValueError(f"slot must have shape ({self.B},), got {slot.shape}")
+        return slot
+
+    def interpolate(self, t, slot):
+        slot = self._slots(slot)
         _check(self._lib.pnode_interpolate(self._h, _dp(_f64(t, (self.B,))), slot.ctypes.data_as(C.POINTER(C.c_int32))))
 
     def checkpoint_at_step(self, slot):
-        slot = np.ascontiguousarray(slot, dtype=np.int32)
+        slot = self._slots(slot)
         _check(self._lib.pnode_checkpoint_at_step(self._h, slot.ctypes.data_as(C.POINTER(C.c_int32))))
 
     def solve_adaptive_save_at(self, save_at, dt0, control, numerical_zero, max_attempts=0, device_controller=False):
@@ -234,6 +259,8 @@ class Batch:
         device). Returns (num_steps, num_attempts, failed)."""
         save_at = _f64(save_at)
         per_traj = int(save_at.ndim == 2)
+        if save_at.ndim not in (1, 2) or (per_traj and save_at.shape[0] != self.B):
+            raise ValueError(f"save_at must have shape (K+1,) or ({self.B}, K+1), got {save_at.shape}")
         num_save = save_at.shape[-1]
         ctrl = PnodeControl(control.safety, control.factor_min, control.factor_max, control.power_integral_unscaled,
                             control.power_proportional_unscaled, int(control.clip), 0)
@@ -286,7 +313,7 @@ class Batch:
         return out
 
     def smooth_checkpoint_means(self, num_filled):
-        nf = np.ascontiguousarray(num_filled, dtype=np.int32)
+        nf = self._slots(num_filled)
         out = np.zeros((self.B, self.K + 1, self.n, self.d))
         _check(self._lib.pnode_smooth_checkpoint_means(self._h, nf.ctypes.data_as(C.POINTER(C.c_int32)), _dp(out)))
         return out

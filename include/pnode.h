@@ -186,13 +186,10 @@ int pnode_smooth_checkpoint_means(pnode_batch* h, const int32_t* num_filled, dou
 /* Timing of the device work of the most recent attempt_step (HIP events on the handle's stream),
  * in milliseconds; used by bench.py for the roofline line. Needs pnode_set_phase_timing(h, 1). */
 int pnode_last_step_ms(pnode_batch* h, float* ms_out);
-/* Diagnostics (dense): raw 64-bit words of a trajectory's scratch area (in-kernel cycle stamps of
- * timing-only builds, PNODE_ABLATE & 128). Never part of a result. */
-int pnode_debug_read_scratch(pnode_batch* h, int32_t b, int32_t offset_words, int32_t count, uint64_t* out);
 /* Dense model only, A/B testing of the device paths (all of them HIP, none a CPU fallback): 0 = dispatch by shape
  * (fused one-wavefront kernel for (nu+1)*d <= 32, register-resident MFMA kernels, HBM-tiled large-D kernels, generic
  * kernels otherwise), 1 = generic kernels, 2 = large-D kernels (PNODE_EINVAL if the shape is not supported there).
- * The environment variable PNODE_DENSE_PATH=1|2 applies the same choice to every handle created afterwards. */
+ * No environment variable influences the library: the choice is per handle, through this call only. */
 int pnode_set_generic_path(pnode_batch* h, int32_t enabled);
 /* Enables HIP-event timing of attempt_step (all models). Dense model: also record HIP events between the kernels of a step (on the handle's stream) and
  * read the durations of the last attempt, ms_out[4] = {begin, lq_input, lq, correct}. */

@@ -581,7 +581,7 @@ def test_dense_fixedpoint_smoother_vs_oracle(hip_lib, case, monkeypatch):
         vf, nu, corr, u0s, tol, save_at, dt0 = V.brusselator(4), 3, "ts1", [brusselator_y0(4)], 1e-5, np.linspace(0, 1.0, 6), 0.01
     elif case in ("brusselator16_large", "brusselator16_generic"):
         # d = 32, D = 128: the large-D kernels are the default for the smoother; "generic" pins the reference kernels
-        monkeypatch.setenv("PNODE_DENSE_PATH", "2" if case.endswith("large") else "1")
+        monkeypatch.setattr(_backend, "dense_path", 2 if case.endswith("large") else 1)
         vf, nu, corr, u0s, tol, save_at, dt0 = V.brusselator(16), 3, "ts1", [brusselator_y0(16)], 1e-4, np.linspace(0, 0.5, 4), 0.01
     elif case == "rigid":
         vf, nu, corr, u0s, tol, save_at, dt0 = V.rigid_body(), 2, "ts1", [np.array([1.0, 0.0, 0.9])], 1e-4, np.linspace(0, 4.0, 5), 0.1
@@ -641,7 +641,7 @@ def test_uncalibrated_dense_on_the_mfma_and_large_paths(hip_lib, path, monkeypat
     """calibrate="none" with the dense model at Brusselator N=16 (d=32, D=128): the register-resident MFMA kernels
     (default) and the large-D kernels (forced), adaptive solve with the fixed output scale against the oracle."""
     if path:
-        monkeypatch.setenv("PNODE_DENSE_PATH", str(path))
+        monkeypatch.setattr(_backend, "dense_path", path)
     N = 16
     vf = V.brusselator(N)
     impl.select("dense", ode_shape=(2 * N,))
