@@ -8,9 +8,12 @@ accepts/rejects and proposes the next step sizes. Inputs are resident in HBM bef
 `value` = accepted trajectory-steps of all ranks / wall time of the slowest rank.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu-baseline]
-Multi-GPU: launched by torch.distributed.run, one rank per GPU; the trajectories are sharded (weak
-scaling: B per GPU fixed), no data-path collective; RCCL is used only for the barrier, the MAX/SUM of
-the timings and the final gather of per-trajectory results.
+Multi-GPU: launched by torch.distributed.run, one rank per GPU. Default `--scaling strong`: the BASELINE
+configuration, ONE batch of --batch (1024) trajectories sharded contiguously over the ranks
+(`sharding.shard_bounds`: 128 per GPU at 8 GPUs), no data-path collective. `--scaling weak` keeps --batch
+trajectories per GPU instead. torch.distributed (the driver's launch contract) carries the barrier and the
+MAX/SUM of the timings; the path's own exchange, the final gather of per-trajectory results, is one
+ncclAllGather through the ctypes binding of librccl.so in probdiffeq_hip/sharding.py.
 """
 
 import argparse
@@ -120,11 +123,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=1024, help="trajectories per GPU")
+    ap.add_argument("--batch", type=int, default=1024,
+                    help="trajectories in the global batch (--scaling strong) or per GPU (--scaling weak)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="strong: ONE batch of --batch trajectories sharded over the GPUs (BASELINE config 4); weak: --batch per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--model", default="dense", choices=["dense", "isotropic"])
     ap.add_argument("--diag-fixed-dt", type=float, default=0.0,
-                    help="diagnostics only: constant step size, controller bypassed (used with PNODE_ABLATE timing runs)")
+                    help="diagnostics only: constant step size, controller bypassed")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -152,8 +158,18 @@ def main():
     from probdiffeq_hip import _backend, ivpsolve, ivpsolvers
     from probdiffeq_hip.impl import impl
 
-    B = args.batch
-    vf, tcs = problem_batch(B, rank * B, world * B)
+    from probdiffeq_hip import sharding
+
+    if args.scaling == "strong":
+        total = args.batch
+        lo, hi = sharding.shard_bounds(total, world, rank)
+    else:
+        total = args.batch * world
+        lo, hi = rank * args.batch, (rank + 1) * args.batch
+    B = hi - lo
+    if B <= 0:
+        raise SystemExit(f"rank {rank}: empty shard ({total} trajectories over {world} ranks)")
+    vf, tcs = problem_batch(B, lo, total)
     d = vf.d
     D = (NU + 1) * d
     dense = args.model == "dense"
@@ -213,11 +229,34 @@ def main():
         cnt = torch.tensor([accepted], dtype=torch.float64, device=tdev)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         accepted = int(cnt.item())
-        # the path's only exchange: gather per-trajectory results (here: current state u, [B, d])
-        from probdiffeq_hip import sharding
+        # the path's only exchange: gather per-trajectory results (here: current state u, [B, d]) -- one ncclAllGather over
+        # RCCL through ctypes; the 128-byte ncclUniqueId travels over the process group the launch contract created
+        u_local = batch.read_mean(0)[:, 0, :].copy()
+        bmax = torch.tensor([B], dtype=torch.int64, device=tdev)
+        dist.all_reduce(bmax, op=dist.ReduceOp.MAX)
+        pad = np.zeros((int(bmax.item()), d))
+        pad[:B] = u_local  # shards differ by at most one trajectory: pad to equal shapes
+        gather_how = "rccl-ctypes"
+        try:
+            if backend != "nccl":
+                raise RuntimeError("rehearsal backend")
 
-        gathered = sharding.gather_results(batch.read_mean(0)[:, 0, :].copy(), device=tdev)
-        assert gathered.shape == (world * B, d)
+            def via_group(raw):
+                box = [raw]
+                dist.broadcast_object_list(box, src=0)
+                return box[0]
+
+            comm = sharding.RcclGather(rank, world, local, exchange_id=via_group)
+            gathered = sharding.gather_results(pad, comm)
+            comm.close()
+        except Exception as e:  # keep the scaling run alive and say so in the line
+            gather_how = f"torch.distributed fallback ({type(e).__name__}: {e})"
+            t = torch.from_numpy(pad).to(tdev)
+            outl = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(outl, t)
+            gathered = torch.cat(outl, dim=0).cpu().numpy()
+        assert gathered.shape == (world * pad.shape[0], d)
+        assert np.array_equal(gathered[rank * pad.shape[0]:rank * pad.shape[0] + B], u_local)
 
     if rank == 0:
         K = args.steps
@@ -230,14 +269,16 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / K,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"Brusselator N=32 (d=64), nu=3, {'dense EKF1' if dense else 'isotropic EKF0'}, dynamic "
-                                   f"calibration, filter, tol 1e-6, dt0 0.01, y0 phase family; {B} trajectories per GPU",
-                       "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"shard{world}",
-                       "attempted_steps_per_s": B * world * K / elapsed,
+                                   f"calibration, filter, tol 1e-6, dt0 0.01, y0 phase family; global batch {total}"
+                                   + (f", {B} trajectories on rank 0" if world > 1 else ""),
+                       "batch_per_gpu": B, "global_batch": total, "parallelism": f"shard{world}",
+                       "gather": gather_how if world > 1 else None,
+                       "attempted_steps_per_s": total * K / elapsed,
                        "device_ms_per_step": dev_ms / K},
         }
         if dense:

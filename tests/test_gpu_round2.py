@@ -1,0 +1,106 @@
+"""Round-2 GPU parity cases: terminal values against the reference's golden step counts, BASELINE config 1 as a whole
+solve, shard invariance of the headline batch."""
+
+import numpy as np
+import pn_oracle as po
+import pytest
+import scipy.integrate
+from helpers import brusselator_y0, oracle_problem, tcoeffs
+from probdiffeq_hip import ivpsolve, ivpsolvers, sharding, taylor
+from probdiffeq_hip import vector_fields as V
+from probdiffeq_hip.impl import impl
+
+pytestmark = pytest.mark.gpu
+
+
+def relmax(a, b):
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+@pytest.mark.parametrize("N", [16, 32])
+def test_terminal_values_golden_step_counts(hip_lib, golden, N):
+    """solve_adaptive_terminal_values as the reference calls it (experiments/4_brusselator/run.py:82-99): isotropic
+    nu=4 EKF0, fixed-point strategy, dynamic calibration, tol 1e-8, dt0 0.01, t in [0, 10]. The accepted-step count is
+    pinned by the reference's committed `data_textbook.npy` (`num_steps`), the terminal value by the oracle."""
+    g = golden["brusselator"]
+    vf = V.brusselator(N)
+    impl.select("isotropic", ode_shape=(2 * N,))
+    solver = ivpsolvers.solver_dynamic(ivpsolvers.strategy_fixedpoint(ivpsolvers.prior_ibm(4), ivpsolvers.correction_ts0(ode_order=1)))
+    asolver = ivpsolve.adaptive(solver, atol=1e-8, rtol=1e-8, control=ivpsolve.control_proportional_integral())
+    tcs = taylor.odejet_unroll(vf, [brusselator_y0(N)], num=4)
+    init = solver.initial_condition(tcs, 1.0)
+    sol = ivpsolve.solve_adaptive_terminal_values(vf, init, t0=0.0, t1=10.0, dt0=0.01, adaptive_solver=asolver)
+    i = list(g["N"]).index(N)
+    assert int(sol.num_steps) == int(g["num_steps_terminal"][i])
+    assert sol.u.shape == (2 * N,) and float(sol.t) == 10.0
+    # the checkpointed solve of the same configuration ends in the same state (golden `ys[-1]`)
+    assert np.max(np.abs(sol.u - g[f"ys_N{N}"][-1])) < 1e-9
+    cfg = po.SolverConfig(nu=4, model="isotropic", correction="ts0", strategy="fixedpoint", calibration="dynamic")
+    osol = po.solve_adaptive_save_at(cfg, po.AdaptiveConfig(1e-8, 1e-8), oracle_problem(vf), po.initial_state(cfg, tcs, 0.0),
+                                     np.array([0.0, 10.0]), 0.01)
+    assert int(osol.num_steps[-1]) == int(sol.num_steps)
+    assert relmax(sol.u, osol.u[-1]) < 1e-9
+
+
+def test_config1_van_der_pol_mu1_whole_solve(hip_lib):
+    """BASELINE config 1 (/root/reference/experiments/old/7_node/node.py:23-37,88-91): Van der Pol mu = 1 in first-order
+    form (d = 2), y0 = (2, 0), t in [0, 6.3]; nu = 3 IWP prior, EKF0, isotropic, single trajectory, tol 1e-6, dt0 0.1.
+    Whole adaptive solve against the oracle (identical decisions, means 1e-8) and against scipy (reference-test style)."""
+    vf = V.van_der_pol_order1(1.0)
+    impl.select("isotropic", ode_shape=(2,))
+    save_at = np.linspace(0.0, 6.3, 22)
+    tcs = tcoeffs(vf, [np.array([2.0, 0.0])], 3)
+    truth = scipy.integrate.solve_ivp(lambda t, y: vf(y), (0.0, 6.3), [2.0, 0.0], method="DOP853", rtol=1e-12, atol=1e-12,
+                                      t_eval=save_at).y.T
+    for strat, ostrat in (("filter", "filter"), ("fixedpoint", "fixedpoint")):
+        strategy = getattr(ivpsolvers, f"strategy_{strat}")(ivpsolvers.prior_ibm(3), ivpsolvers.correction_ts0())
+        solver = ivpsolvers.solver_dynamic(strategy)
+        asolver = ivpsolve.adaptive(solver, atol=1e-6, rtol=1e-6)
+        init = solver.initial_condition(tcs, 1.0)
+        cfg = po.SolverConfig(nu=3, model="isotropic", correction="ts0", strategy=ostrat, calibration="dynamic")
+        osol = po.solve_adaptive_save_at(cfg, po.AdaptiveConfig(1e-6, 1e-6), oracle_problem(vf), po.initial_state(cfg, tcs, 0.0),
+                                         save_at, 0.1)
+        for dev in (False, True):
+            sol = ivpsolve.solve_adaptive_save_at(vf, init, save_at=save_at, dt0=0.1, adaptive_solver=asolver, device_controller=dev)
+            assert np.array_equal(sol.num_steps, osol.num_steps), (strat, dev)
+            ref = po.markov_marginals_reverse(cfg, osol)[:, 0] if strat == "fixedpoint" else osol.u
+            assert relmax(sol.u, ref) < 1e-8, (strat, dev)
+            assert np.allclose(sol.u, truth, atol=1e-3, rtol=1e-3), (strat, dev)  # sqrt(tol), tests/test_ivpsolvers.py:52
+    # terminal values / every step / fixed grid drivers on the same problem
+    term = ivpsolve.solve_adaptive_terminal_values(vf, init, t0=0.0, t1=6.3, dt0=0.1, adaptive_solver=asolver)
+    assert int(term.num_steps) == int(osol.num_steps[-1])
+    fsolver = ivpsolvers.solver_dynamic(ivpsolvers.strategy_filter(ivpsolvers.prior_ibm(3), ivpsolvers.correction_ts0()))
+    every = ivpsolve.solve_adaptive_save_every_step(vf, fsolver.initial_condition(tcs, 1.0), t0=0.0, t1=6.3, dt0=0.1,
+                                                    adaptive_solver=ivpsolve.adaptive(fsolver, atol=1e-6, rtol=1e-6))
+    assert every.t[-1] == 6.3 and len(every.t) >= int(osol.num_steps[-1])
+    fixed = ivpsolve.solve_fixed_grid(vf, fsolver.initial_condition(tcs, 1.0), grid=every.t, solver=fsolver)
+    assert relmax(fixed.u[:-1], every.u[:-1]) < 1e-9  # the replay of the accepted grid reproduces the adaptive run
+
+
+def test_headline_batch_is_shard_invariant(hip_lib):
+    """the 1024-trajectory headline batch (Brusselator N=32, nu=3, dense EKF1) solved as ONE batch and as
+    8 shards of 128 (`sharding.shard_bounds`, the split bench.py --scaling strong uses at 8 GPUs), one after the other on
+    one GPU: accepted steps, attempts, times and means bit-identical."""
+    N, NU, TOL, DT0, B, W = 32, 3, 1e-6, 0.01, 1024, 8
+    vf = V.brusselator(N)
+    x = np.linspace(0.0, 1.0, N)
+    ph = 2.0 * np.pi * np.arange(B) / B
+    y0 = np.concatenate([1.0 + np.sin(2 * np.pi * x[None, :] + ph[:, None]), 3.0 * np.ones((B, N))], axis=1)
+    impl.select("dense", ode_shape=(2 * N,))
+    solver = ivpsolvers.solver_dynamic(ivpsolvers.strategy_filter(ivpsolvers.prior_ibm(NU), ivpsolvers.correction_ts1()))
+    asolver = ivpsolve.adaptive(solver, atol=TOL, rtol=TOL)
+    save_at = np.array([0.0, 0.02, 0.05])
+
+    def run(ys):
+        init = solver.initial_condition(taylor.odejet_padded_scan(vf, [ys], num=NU), 1.0)
+        return ivpsolve.solve_adaptive_save_at(vf, init, save_at=save_at, dt0=DT0, adaptive_solver=asolver)
+
+    whole = run(y0)
+    for rank in range(W):
+        lo, hi = sharding.shard_bounds(B, W, rank)
+        assert hi - lo == 128
+        part = run(y0[lo:hi])
+        assert np.array_equal(part.num_steps, whole.num_steps[lo:hi]), rank
+        assert np.array_equal(part.num_attempts, whole.num_attempts[lo:hi]), rank
+        assert np.array_equal(part.u, whole.u[lo:hi]), rank
+        assert np.array_equal(part.output_scale, whole.output_scale[lo:hi]), rank

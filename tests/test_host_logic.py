@@ -184,36 +184,61 @@ def test_sharding_helpers():
         assert covered == list(range(total))
         inter = np.sort(np.concatenate([sharding.interleaved_indices(total, world, r) for r in range(world)]))
         assert np.array_equal(inter, np.arange(total))
-    assert sharding.gather_results(np.arange(3.0)) is not None
+    assert sharding.gather_results(np.arange(3.0)) is not None  # no communicator: identity
 
 
-def _gloo_worker(rank, world, port, out_dir):
+def _sharded_worker(rank, world, port, out_dir):
+    """One rank of the sharded path with the device replaced by its checker (no GPU here): Taylor initialisation of the
+    local shard (product host code), the oracle's adaptive solve of every local trajectory, then the result gather."""
+    import pn_oracle as po
     import torch.distributed as dist
+    from helpers import oracle_problem
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     total = 6
     lo, hi = sharding.shard_bounds(total, world, rank)
-    vf = V.brusselator(4)
-    y0 = np.stack([brusselator_y0(4, 2 * np.pi * b / total) for b in range(lo, hi)])
-    # host part of the sharded path: Taylor initialisation of the local shard, then the result gather
-    tc = np.stack(taylor.odejet_unroll(vf, [y0], num=3), axis=1)
-    full = sharding.gather_results(tc)
+    u, steps = _solve_shard(lo, hi, total)
+    comm = sharding.GlooGather()
+    full_u = sharding.gather_results(u, comm)
+    full_steps = sharding.gather_results(steps, comm)
+    # the TCP hand-over of the ncclUniqueId that the RCCL gather uses (the 128 bytes themselves need a GPU to mean anything)
+    blob = bytes(range(128)) if rank == 0 else None
+    got = sharding._tcp_exchange(blob, rank, world, "127.0.0.1", port + 29)
+    assert got == bytes(range(128))
     if rank == 0:
-        np.save(os.path.join(out_dir, "gathered.npy"), full)
+        np.save(os.path.join(out_dir, "u.npy"), full_u)
+        np.save(os.path.join(out_dir, "steps.npy"), full_steps)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_gather_equals_single_process(tmp_path):
-    """The N>1 path on CPU (gloo, world_size 2): shard -> per-rank work -> all_gather == unsharded."""
+def _solve_shard(lo, hi, total):
+    import pn_oracle as po
+    from helpers import oracle_problem
+
+    vf = V.brusselator(4)
+    y0 = np.stack([brusselator_y0(4, 2 * np.pi * b / total) for b in range(lo, hi)])
+    tcs = taylor.odejet_unroll(vf, [y0], num=3)
+    cfg = po.SolverConfig(nu=3, model="isotropic", correction="ts0", strategy="filter", calibration="dynamic")
+    save_at = np.linspace(0.0, 0.5, 4)
+    us, steps = [], []
+    for b in range(hi - lo):
+        sol = po.solve_adaptive_save_at(cfg, po.AdaptiveConfig(1e-5, 1e-5), oracle_problem(vf),
+                                        po.initial_state(cfg, [c[b] for c in tcs], 0.0), save_at, 0.01)
+        us.append(sol.u)
+        steps.append(np.asarray(sol.num_steps, dtype=np.int64))
+    return np.stack(us), np.stack(steps)
+
+
+def test_two_rank_sharded_solve_and_gather_equals_single_process(tmp_path):
+    """The N>1 path on CPU (gloo, world_size 2): shard_bounds -> per-rank solve of the shard -> all_gather of the
+    per-trajectory results == the unsharded run, bit for bit (no exchange during integration)."""
     import torch.multiprocessing as mp
 
     port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_gloo_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    gathered = np.load(tmp_path / "gathered.npy")
-    vf = V.brusselator(4)
-    y0 = np.stack([brusselator_y0(4, 2 * np.pi * b / 6) for b in range(6)])
-    ref = np.stack(taylor.odejet_unroll(vf, [y0], num=3), axis=1)
-    assert np.array_equal(gathered, ref)
+    mp.spawn(_sharded_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    u_ref, steps_ref = _solve_shard(0, 6, 6)
+    assert np.array_equal(np.load(tmp_path / "u.npy"), u_ref)
+    assert np.array_equal(np.load(tmp_path / "steps.npy"), steps_ref)

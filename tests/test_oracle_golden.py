@@ -88,3 +88,25 @@ def test_rigid_body_and_pleiades_definitions(golden):
     y0 = g["ys"][0]
     s = solve_ivp(lambda t, y: vf(y), (0, 3), y0, method="DOP853", atol=1e-12, rtol=1e-12, t_eval=g["ts"])
     assert np.max(np.abs(s.y.T - g["ys"])) < 1e-6
+
+
+def test_config1_van_der_pol_mu1_oracle_against_scipy():
+    """BASELINE config 1 (experiments/old/7_node/node.py:23-37,88-91): Van der Pol mu=1 (d=2), nu=3, EKF0, isotropic,
+    tol 1e-6 on the oracle, against an independent Runge-Kutta truth at sqrt(tol) like tests/test_ivpsolvers.py:52."""
+    import scipy.integrate
+    from helpers import oracle_problem, tcoeffs
+    from probdiffeq_hip import vector_fields as V
+
+    vf = V.van_der_pol_order1(1.0)
+    save_at = np.linspace(0.0, 6.3, 22)
+    tcs = tcoeffs(vf, [np.array([2.0, 0.0])], 3)
+    truth = scipy.integrate.solve_ivp(lambda t, y: vf(y), (0.0, 6.3), [2.0, 0.0], method="DOP853", rtol=1e-12, atol=1e-12,
+                                      t_eval=save_at).y.T
+    for strategy in ("filter", "fixedpoint"):
+        cfg = po.SolverConfig(nu=3, model="isotropic", correction="ts0", strategy=strategy, calibration="dynamic")
+        sol = po.solve_adaptive_save_at(cfg, po.AdaptiveConfig(1e-6, 1e-6), oracle_problem(vf), po.initial_state(cfg, tcs, 0.0),
+                                        save_at, 0.1)
+        u = po.markov_marginals_reverse(cfg, sol)[:, 0] if strategy == "fixedpoint" else sol.u
+        assert np.allclose(u, truth, atol=1e-3, rtol=1e-3)
+        assert np.max(np.abs(u - truth)) < 1e-4  # (2e-6 .. 3e-6 in practice)
+        assert 300 < int(sol.num_steps[-1]) < 600
