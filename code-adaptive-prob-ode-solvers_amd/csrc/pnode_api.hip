@@ -979,6 +979,7 @@ int pnode_set_generic_path(pnode_batch* h, int32_t enabled) {
   h->dn.force_generic = enabled == 1 || h->dn.fixedpoint;  // the register-resident MFMA kernels have no extra-row LQ
   h->dn.user_generic = enabled == 1;
   h->dn.force_large = enabled == 2;
+  h->dn.lq_legacy = enabled == 3;
   return PNODE_OK;
 }
 
@@ -997,5 +998,13 @@ int pnode_last_phase_ms(pnode_batch* h, float* ms_out) {
 }
 
 void* pnode_stream(pnode_batch* h) { return h ? (void*)h->stream : nullptr; }
+
+int pnode_lq_schedule(int32_t num_strips, int32_t panels_per_pass, int8_t* out, int32_t capacity) {
+  if (!out || capacity < int32_t(sizeof(LqSchedule))) return fail(PNODE_EINVAL, "buffer too small for the schedule table");
+  LqSchedule S;
+  if (!lq_build_schedule(num_strips, panels_per_pass, &S)) return fail(PNODE_EINVAL, "no schedule for this shape");
+  std::memcpy(out, &S, sizeof(S));
+  return int(sizeof(S));
+}
 
 }  // extern "C"

@@ -1,0 +1,437 @@
+// Time update of the dense EKF1 fast path, ONE launch: blocked row-Householder LQ of the D x 2D stack [T0 | Mt] with
+// 64-row passes (NP = 4 panels of 16 rows), one workgroup of 8 wavefronts per trajectory.
+//
+//   * Every wavefront owns at most one 16-row strip of Mt at a time, resident in registers in the MFMA operand layout
+//     (pnode_mfma_common.hpp). A strip is read from HBM once per PASS (64 rows of reflectors are applied to it while it
+//     stays in registers) and the strips that become the panels of the next pass never leave the chip: the wavefront
+//     that updated them last keeps them and factorises them in place ("carried" strips). Per trajectory the trailing
+//     matrix moves (D/64 - 1)(D/64 - 2)/2 * 64 rows in and out instead of 8 x that with 32-row passes and no carry.
+//   * A panel is factorised by ONE wavefront, in registers, in the strip layout itself: lane (r, g) holds row r, the
+//     pivot row is broadcast inside each 16-lane DPP row by the DPP operand of v_fmac_f64 (row_newbcast: one instruction
+//     per element for the dot products and one for the update), the four column groups are summed by one
+//     v_mfma_f64_16x16x4 against a matrix of ones. No LDS round trip, no barrier inside a panel; the compact-WY factor is
+//     built by the forward recurrence of dlarft during the sweep. The other wavefronts meanwhile apply the panels that
+//     are already published (LDS) to the strips they hold: the chain of the 4 panels of a pass runs beside MFMA work.
+//   * Which wavefront holds which strip when is a small table built on the host (lq_build_schedule, checked by a CPU test).
+//
+// Reference anchors: strategy_filter (/root/reference/experiments/1_van_der_pol/vdp.py:65) as probdiffeq runs it (sqrt
+// time update by QR of the stacked factor); arithmetic restated in oracle/pn_oracle.py (predict_sqrt).
+#include <cstring>
+
+#include "pnode_mfma_common.hpp"
+
+namespace pnode {
+
+bool lq_build_schedule(int DT, int NP, LqSchedule* S) {
+  if (NP < 1 || NP > kLqMaxNP || DT % NP != 0 || DT / NP > kLqMaxPass || DT / NP < 1) return false;
+  std::memset(S, -1, sizeof(*S));
+  S->npass = int8_t(DT / NP);
+  S->np = int8_t(NP);
+  S->dt = int8_t(DT);
+  S->pad = 0;
+  for (int k = 0; k < NP; ++k) S->pw[0][k] = int8_t(k);
+  for (int P = 0; P < S->npass; ++P) {
+    bool panel_wave[kLqWaves] = {}, holding[kLqWaves] = {};
+    for (int k = 0; k < NP; ++k) {
+      if (S->pw[P][k] < 0 || S->pw[P][k] >= kLqWaves || panel_wave[S->pw[P][k]]) return false;
+      panel_wave[S->pw[P][k]] = true;
+    }
+    auto carried = [&](int s) { return P + 1 < S->npass && s >= NP * (P + 1) && s < NP * (P + 2); };
+    int lst[64], n = 0;
+    for (int s = NP * (P + 2); s < DT; ++s) lst[n++] = s;                                    // plain trailing strips first
+    for (int s = NP * (P + 1); s < NP * (P + 2) && s < DT; ++s) lst[n++] = s;                  // the next pass's panels last
+    int pos = 0;
+    auto give = [&](int w, int s) {
+      if (carried(s)) {
+        holding[w] = true;
+        S->pw[P + 1][s - NP * (P + 1)] = int8_t(w);
+      }
+    };
+    for (int w = 0; w < kLqWaves && pos < n; ++w)
+      if (!panel_wave[w]) {
+        S->shadow[P][w] = int8_t(lst[pos]);
+        give(w, lst[pos++]);
+      }
+    int rd = 0;
+    while (pos < n) {
+      if (rd >= kLqMaxRounds) return false;
+      bool any = false;
+      for (int w = 0; w < kLqWaves && pos < n; ++w)
+        if (!holding[w]) {
+          S->round[P][rd][w] = int8_t(lst[pos]);
+          give(w, lst[pos++]);
+          any = true;
+        }
+      if (!any) return false;
+      ++rd;
+    }
+    S->nrounds[P] = int8_t(rd);
+  }
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Register-resident panel factorisation in the strip layout.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int C>
+__device__ __forceinline__ double bcast16(double v) {  // lane C of every 16-lane DPP row -> all lanes of that row
+  return __builtin_amdgcn_update_dpp(v, v, 0x150 + C, 0xf, 0xf, false);
+}
+
+// acc_i += x_e(lane C of the row) * x_e(this lane): the dot product of every row with row C, partial over this lane's columns.
+// (s_nop 1: a VGPR written by a VALU instruction needs two wait states before a DPP read; nothing pads inside asm.)
+template <int C>
+__device__ __forceinline__ void dot16(double& a0, double& a1, double& a2, double& a3, double x0, double x1, double x2, double x3, double x4, double x5, double x6, double x7, double x8, double x9, double x10, double x11, double x12, double x13, double x14, double x15) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_fmac_f64_dpp %0, %4, %4 row_newbcast:%20 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %1, %5, %5 row_newbcast:%20 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %2, %6, %6 row_newbcast:%20 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %3, %7, %7 row_newbcast:%20 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %8, %8 row_newbcast:%20 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %1, %9, %9 row_newbcast:%20 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %2, %10, %10 row_newbcast:%20 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %3, %11, %11 row_newbcast:%20 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %12, %12 row_newbcast:%20 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %1, %13, %13 row_newbcast:%20 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %2, %14, %14 row_newbcast:%20 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %3, %15, %15 row_newbcast:%20 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %16, %16 row_newbcast:%20 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %1, %17, %17 row_newbcast:%20 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %2, %18, %18 row_newbcast:%20 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %3, %19, %19 row_newbcast:%20 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0"
+      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)
+      : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(x4), "v"(x5), "v"(x6), "v"(x7), "v"(x8), "v"(x9), "v"(x10), "v"(x11), "v"(x12), "v"(x13), "v"(x14), "v"(x15), "i"(C));
+}
+// x_e += x_e(lane C of the row) * nws  (nws = 0 on the lanes whose row is not updated, lane C included)
+template <int C>
+__device__ __forceinline__ void upd16(double& x0, double& x1, double& x2, double& x3, double& x4, double& x5, double& x6, double& x7, double& x8, double& x9, double& x10, double& x11, double& x12, double& x13, double& x14, double& x15, double nws) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_fmac_f64_dpp %0, %0, %16 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %1, %1, %16 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %2, %2, %16 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %3, %3, %16 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %4, %4, %16 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %5, %5, %16 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %6, %6, %16 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %7, %7, %16 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %8, %8, %16 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %9, %9, %16 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %10, %10, %16 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %11, %11, %16 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %12, %12, %16 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %13, %13, %16 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %14, %14, %16 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %15, %15, %16 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0"
+      : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7), "+v"(x8), "+v"(x9), "+v"(x10), "+v"(x11), "+v"(x12), "+v"(x13), "+v"(x14), "+v"(x15)
+      : "v"(nws), "i"(C));
+}
+
+template <int M, int C>
+__device__ __forceinline__ void tf_accumulate(double& acc, double u, const double (&tfrow)[kNB]) {
+  if constexpr (M < C) {
+    acc = fma(tfrow[M], bcast16<M>(u), acc);
+    tf_accumulate<M + 1, C>(acc, u, tfrow);
+  }
+}
+
+// Pivot C of the sweep. On entry rows 0 .. C are final (row C received its last update at pivot C - 1).
+//   v_C = [e_C ; scl_C x_C]  (x_C stays unscaled in the registers),  H_C = I - tau_C v_C^T v_C.
+// tpp_row[C] <- T[row r][column C of the panel]  (beta on the diagonal, -w below, 0 above), staged in LDS
+// tfrow[C] <- Tf[r][C] of the compact-WY factor, H_0 ... H_C = I - V^T Tf V  (forward recurrence, dlarft)
+template <int C, int DT>
+__device__ __forceinline__ void pivot_step(double (&X)[4 * DT], double (&tfrow)[kNB], double* __restrict__ tpp_row, double& myscl,
+                                           double alpha, int r_) {
+  int r = r_;
+  asm volatile("" : "+v"(r));  // opaque: the per-pivot lane predicates are formed here, not hoisted out of the pass loop
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+  for (int e = 0; e < 4 * DT; e += 16)
+    dot16<C>(a0, a1, a2, a3, X[e], X[e + 1], X[e + 2], X[e + 3], X[e + 4], X[e + 5], X[e + 6], X[e + 7], X[e + 8], X[e + 9],
+             X[e + 10], X[e + 11], X[e + 12], X[e + 13], X[e + 14], X[e + 15]);
+  const double part = (a0 + a1) + (a2 + a3);
+  // sum over the four column groups: D[i][j] = sum_k 1 * part(lane (j, k)) -> every lane of row r holds x_r . x_C
+  const double4_t z4 = {0.0, 0.0, 0.0, 0.0};
+  const double4_t d4 = MFMA64(1.0, part, z4);
+  const double dotv = d4[0];
+  const double xx = bcast16<C>(dotv);  // |x_C|^2
+  double tauc = 0.0, scale = 0.0, beta = alpha;
+  {
+    const double nrm2 = fma(alpha, alpha, xx);
+    const double rs = fast_rsqrt(nrm2);
+    const double sgn = copysign(1.0, alpha);
+    const double t1 = fma(fabs(alpha), rs, 1.0);
+    const bool refl = xx != 0.0;  // (NaN != 0: a NaN row propagates, like the reference's QR)
+    beta = refl ? -sgn * nrm2 * rs : alpha;
+    tauc = refl ? t1 : 0.0;
+    scale = refl ? sgn * rs * fast_rcp(t1) : 0.0;
+  }
+  const double w = tauc * scale * dotv;  // (the rows of one panel have no T0 entry in each other's columns)
+  const double nws = (r > C) ? -(w * scale) : 0.0;
+  tpp_row[C] = (r > C) ? -w : ((r == C) ? beta : 0.0);  // (the four lanes of a row store the same value)
+  {
+    const double u = (r < C) ? myscl * scale * dotv : 0.0;  // v_r . v_C for the finished reflectors r < C
+    double acc = 0.0;
+    tf_accumulate<0, C>(acc, u, tfrow);
+    tfrow[C] = (r < C) ? -tauc * acc : ((r == C) ? tauc : 0.0);
+  }
+  myscl = (r == C) ? scale : myscl;
+#pragma unroll
+  for (int e = 0; e < 4 * DT; e += 16)
+    upd16<C>(X[e], X[e + 1], X[e + 2], X[e + 3], X[e + 4], X[e + 5], X[e + 6], X[e + 7], X[e + 8], X[e + 9], X[e + 10], X[e + 11],
+             X[e + 12], X[e + 13], X[e + 14], X[e + 15], nws);
+}
+
+template <int C, int DT>
+__device__ __forceinline__ void pivot_sweep(double (&X)[4 * DT], double (&tfrow)[kNB], double* __restrict__ tpp_row, double& myscl,
+                                            double alpha, int r) {
+  if constexpr (C < kNB) {
+    pivot_step<C, DT>(X, tfrow, tpp_row, myscl, alpha, r);
+    pivot_sweep<C + 1, DT>(X, tfrow, tpp_row, myscl, alpha, r);
+  }
+}
+
+struct Lq3Args {  // ONE by-value kernel argument: the schedule is read through the kernarg segment pointer (scalar loads with
+  DenseView v;    // computed offsets) instead of being copied into SGPRs
+  const StepArg* args;
+  const IwpConst* Kc;
+  LqSchedule S;
+};
+
+template <int DT, int NP, int DD>
+__global__ __launch_bounds__(64 * kLqWaves) void dense_lq3_mfma_kernel(const Lq3Args ka_) {
+  static_assert(DT % 4 == 0, "the HBM strip layout needs D % 64 == 0");
+  static_assert(DT % NP == 0, "whole passes");
+  static_assert((2 * 16 * DD) % (kNB * NP) == 0, "a pass is all below or all beyond column 2d");
+  constexpr int D = 16 * DT, d = 16 * DD;
+  const DenseView& v = ka_.v;
+  const StepArg* __restrict__ args = ka_.args;
+  const IwpConst* __restrict__ Kc = ka_.Kc;
+  // the schedule is indexed with run-time (wave-uniform) indices: read it through the kernarg segment (scalar loads)
+#if defined(__HIP_DEVICE_COMPILE__)
+  const auto* S = &((const __attribute__((address_space(4))) Lq3Args*)__builtin_amdgcn_kernarg_segment_ptr())->S;
+#else
+  const LqSchedule* S = &ka_.S;
+#endif
+  constexpr int LDV = D + 1;  // odd: the A-operand reads of the G phase (16 rows x 2 column groups per half wave) hit 32 bank pairs
+  __shared__ double Vx[NP * kNB * LDV];
+  __shared__ double TfS[NP * kNB * kNB];
+  __shared__ double sclS[NP * kNB];
+  __shared__ double TppS[NP * kNB * kNB];  // diagonal blocks of T, staged for a coalesced write
+  __shared__ double coef[kMaxN * kMaxN];
+  __shared__ double pS[kMaxN];
+
+  const int b = blockIdx.x;
+  const StepArg sarg = args[b];
+  if (!sarg.active) return;
+  const IwpConst& K = *Kc;
+  const int nn = v.n;
+  const double sigma = v.sig_new[b];
+  double* __restrict__ Mt = v.M + size_t(b) * D * D;
+  double* __restrict__ T = v.R + size_t(b) * D * D;
+  const double* __restrict__ Lsrc = v.U + (size_t(sarg.src) * v.B + b) * D * D;
+  double* __restrict__ Ldst = v.U + (size_t(sarg.dst) * v.B + b) * D * D;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  if (tid == 0) {
+    // Mt = (Abar P^-1 (x) I) L is formed while the strips are read: coef[i][k] = Abar[i][k] / p_k
+    double pl[kMaxN], pil[kMaxN];
+    precond_rt(nn, sarg.dt, K, pl, pil);
+    for (int i = 0; i < nn; ++i)
+      for (int k = 0; k < nn; ++k) coef[i * kMaxN + k] = (k >= i) ? K.a[i][k] * pil[k] : 0.0;
+    for (int i = 0; i < kMaxN; ++i) pS[i] = (i < nn) ? pl[i] : 0.0;
+  }
+  __syncthreads();
+
+  auto t0_tile = [&](int row0, int col0) {
+    // T0[row0 + r][col0 + g + 4q] = sigma chol(Qbar)[ib][jb] where the intra-block indices agree
+    double4_t t;
+    const int ib = row0 / d, jb = col0 / d;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      t[q] = (((row0 + r) % d) == ((col0 + g + 4 * q) % d) && jb <= ib) ? sigma * K.qsT[jb][ib] : 0.0;
+    return t;
+  };
+  auto load_strip = [&](int st, double (&X)[4 * DT], bool from_state) {
+    const int j0 = kNB * st;
+    if (from_state) {
+      const int ib = j0 / d, q = (j0 + r) % d;
+#pragma unroll
+      for (int T4 = 0; T4 < DT / 4; ++T4) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) X[16 * T4 + e] = 0.0;
+#pragma unroll 1
+        for (int k = ib; k < nn; ++k) {
+          const double ck = coef[ib * kMaxN + k];
+          const double* __restrict__ lrow = Lsrc + size_t(k * d + q) * D + 16 * g + 64 * T4;
+#pragma unroll
+          for (int e = 0; e < 16; e += 2) {
+            const double2 t2 = *reinterpret_cast<const double2*>(lrow + e);
+            X[16 * T4 + e] = fma(ck, t2.x, X[16 * T4 + e]);
+            X[16 * T4 + e + 1] = fma(ck, t2.y, X[16 * T4 + e + 1]);
+          }
+        }
+      }
+    } else {
+      const double* __restrict__ rowp = Mt + size_t(j0 + r) * D + 16 * g;
+#pragma unroll
+      for (int T4 = 0; T4 < DT / 4; ++T4)
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+          const double2 t2 = *reinterpret_cast<const double2*>(rowp + 64 * T4 + e);
+          X[16 * T4 + e] = t2.x;
+          X[16 * T4 + e + 1] = t2.y;
+        }
+    }
+  };
+  auto store_strip = [&](int st, const double (&X)[4 * DT]) {
+    double* __restrict__ rowp = Mt + size_t(kNB * st + r) * D + 16 * g;
+#pragma unroll
+    for (int T4 = 0; T4 < DT / 4; ++T4)
+#pragma unroll
+      for (int e = 0; e < 16; e += 2) {
+        double2 t2;
+        t2.x = X[16 * T4 + e];
+        t2.y = X[16 * T4 + e + 1];
+        *reinterpret_cast<double2*>(rowp + 64 * T4 + e) = t2;
+      }
+  };
+
+  double X[4 * DT];
+  bool have = false;
+  int mystrip = -1;
+  const int npass = S->npass;
+#pragma unroll 1
+  for (int P = 0; P < npass; ++P) {
+    const int c0 = kNB * NP * P;
+    // Columns >= 2d of L^- are not touched by the measurement update (F = H L^- has 2d non-zero columns): the passes that
+    // produce them write p_row * T straight into the destination slot of the state factor.
+    const bool direct = c0 >= 2 * d;
+    auto carried = [&](int s) { return P + 1 < npass && s >= NP * (P + 1) && s < NP * (P + 2); };
+    auto apply = [&](int k, int st, double (&Xs)[4 * DT]) {
+      const int j0 = kNB * st, cp = c0 + kNB * k;
+      double* Trow = (direct ? Ldst : T) + size_t(j0 + r) * D + cp;
+      const double osc = direct ? pS[(j0 + r) / d] : 1.0;
+      apply_panel_to_strip<DT, LDV>(Xs, Vx + k * kNB * LDV, TfS + k * kNB * kNB, sclS + k * kNB, t0_tile(j0, cp), Trow, osc, r, g);
+    };
+    int mypanel = -1;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) mypanel = (S->pw[P][k] == wv) ? k : mypanel;
+    // task 0: the strip this wavefront holds while the panels of the pass are factorised (a panel of this pass, carried over
+    // from the previous one, or a trailing strip); tasks 1 ..: the strips it processes once all panels are published
+    const int ntasks = 1 + S->nrounds[P];
+#pragma unroll 1
+    for (int task = 0; task < ntasks; ++task) {
+      if (task == 0) {
+        if (mypanel >= 0) {
+          if (P == 0) {
+            mystrip = mypanel;
+            load_strip(mystrip, X, true);
+            have = true;
+          }
+        } else {
+          const int s = S->shadow[P][wv];
+          if (s >= 0) {
+            mystrip = s;
+            load_strip(s, X, P == 0);
+            have = true;
+          }
+        }
+#pragma unroll 1
+        for (int k = 0; k < NP; ++k) {
+          if (have && k > 0) apply(k - 1, mystrip, X);
+          if (k == mypanel) {
+            // ---- factorise my strip in place and publish it as panel k
+            const int cp = c0 + kNB * k;
+            const double alpha = sigma * K.qsT[cp / d][cp / d];
+            double tfrow[kNB], myscl = 0.0;
+#pragma unroll
+            for (int m = 0; m < kNB; ++m) tfrow[m] = 0.0;
+            double* tpp_row = TppS + k * kNB * kNB + r * kNB;
+            __builtin_amdgcn_s_setprio(3);
+            pivot_sweep<0, DT>(X, tfrow, tpp_row, myscl, alpha, r);
+            __builtin_amdgcn_s_setprio(0);
+            double* Vp = Vx + k * kNB * LDV;
+#pragma unroll
+            for (int T4 = 0; T4 < DT / 4; ++T4)
+#pragma unroll
+              for (int e = 0; e < 16; ++e) Vp[r * LDV + 64 * T4 + 16 * g + e] = X[16 * T4 + e];
+            if (g == 0) {
+              sclS[k * kNB + r] = myscl;
+#pragma unroll
+              for (int m = 0; m < kNB; ++m) TfS[k * kNB * kNB + r * kNB + m] = tfrow[m];
+            }
+            {
+              // diagonal block of T: lane (r, g) writes columns 4g .. 4g+3 of row r (zeros above the diagonal)
+              __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (same wavefront wrote the block: program order suffices)
+              double o4[4];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) o4[q] = tpp_row[4 * g + q];
+              const int row = cp + r;
+              double* dstp = (direct ? Ldst : T) + size_t(row) * D + cp + 4 * g;
+              const double osc = direct ? pS[row / d] : 1.0;
+#pragma unroll
+              for (int q = 0; q < 4; q += 2) {
+                double2 t2;
+                t2.x = osc * o4[q];
+                t2.y = osc * o4[q + 1];
+                *reinterpret_cast<double2*>(dstp + q) = t2;
+              }
+            }
+            have = false;
+          }
+          __syncthreads();
+        }
+      } else {
+        const int s = S->round[P][task - 1][wv];
+        if (s >= 0) {
+          mystrip = s;
+          load_strip(s, X, P == 0);
+          have = true;
+        }
+      }
+      if (have) {
+        // the panels not applied yet: the last one for the strip held during the chain, all of them otherwise
+#pragma unroll 1
+        for (int k = (task == 0) ? NP - 1 : 0; k < NP; ++k) apply(k, mystrip, X);
+        if (!carried(mystrip)) {
+          store_strip(mystrip, X);
+          have = false;
+        }
+      }
+      // (a carried strip stays: its wavefront is a panel wavefront of the next pass and takes no further task in this one)
+    }
+    __syncthreads();  // every wavefront is done with this pass's reflectors before the next pass overwrites them
+  }
+}
+
+template <int DT, int NP, int DD>
+static void launch_lq3(const DenseView& v, const StepArg* args, const IwpConst* K, hipStream_t s) {
+  static const LqSchedule sched = [] {  // one table per instantiation (thread-safe static initialisation)
+    LqSchedule t;
+    (void)lq_build_schedule(DT, NP, &t);
+    return t;
+  }();
+  Lq3Args ka{v, args, K, sched};
+  hipLaunchKernelGGL((dense_lq3_mfma_kernel<DT, NP, DD>), dim3(v.B), dim3(64 * kLqWaves), 0, s, ka);
+}
+
+bool dense_lq3_supported(const DenseView& v) {
+  const int DT = v.D / 16, DD = v.d / 16;
+  return v.d % 16 == 0 && ((DT == 8 && DD == 2) || (DT == 12 && DD == 2) || (DT == 16 && DD == 4));
+}
+
+void dense_launch_lq3(const DenseView& v, const StepArg* args, const IwpConst* K, hipStream_t s) {
+  switch (v.D / 16) {
+    case 8: launch_lq3<8, 4, 2>(v, args, K, s); break;
+    case 12: launch_lq3<12, 4, 2>(v, args, K, s); break;
+    case 16: launch_lq3<16, 4, 4>(v, args, K, s); break;
+    default: break;
+  }
+}
+
+}  // namespace pnode

@@ -1,0 +1,99 @@
+// Device helpers shared by the register-resident MFMA kernels (pnode_dense_mfma.hip, pnode_dense_lq.hip).
+#pragma once
+#include "pnode_device.hpp"
+
+namespace pnode {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+#define MFMA64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+
+constexpr int kNB = 16;  // panel height
+
+__device__ __forceinline__ double group16_sum(double v) {
+  v += __shfl_xor(v, 1, kWave);
+  v += __shfl_xor(v, 2, kWave);
+  v += __shfl_xor(v, 4, kWave);
+  v += __shfl_xor(v, 8, kWave);
+  return v;
+}
+
+__device__ __forceinline__ void precond_rt(int n, double dt, const IwpConst& K, double* p, double* pinv) {
+  const double adt = fabs(dt);
+  double pw = sqrt(adt);
+  for (int i = n - 1; i >= 0; --i) {
+    p[i] = pw / K.fact[i];
+    pinv[i] = K.fact[i] / pw;
+    pw *= adt;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Blocked row-Householder LQ:  [T0 | Mt] -> T (lower triangular, written to v.R); 32-row outer blocks (two 16-row panels A, B per pass over the
+// trailing rows, halving the trailing-matrix traffic), DPP reductions and ONE barrier per panel row.
+// Strip register layout for HBM rows (128 contiguous bytes per lane per 64-column super-tile):
+//      X[16 T + 4 j + q] = M[row0 + r][64 T + 16 g + 4 j + q]
+// ---------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// Sum over the 16 lanes of a DPP row; every lane of the row receives the total.
+__device__ __forceinline__ double row16_sum(double v) {
+  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);  // row_half_mirror
+  v += dpp_mov<0x140>(v);  // row_mirror
+  return v;
+}
+
+// One panel's reflectors applied to a register strip X (HBM layout). Writes T[J][P] = T0 - W.
+template <int DT, int LDV>
+__device__ __forceinline__ void apply_panel_to_strip(double (&X)[4 * DT], const double* __restrict__ Vp,
+                                                     const double* __restrict__ Tfp, const double* __restrict__ sclp,
+                                                     double4_t t0v, double* __restrict__ Tout, double out_scale, int r,
+                                                     int g) {
+  double4_t a0 = {0.0, 0.0, 0.0, 0.0}, a1 = a0, a2 = a0, a3 = a0;
+  double4_t sc;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) sc[q] = sclp[g + 4 * q];
+#pragma unroll
+  for (int T = 0; T < DT / 4; ++T) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double* vrow = Vp + r * LDV + 64 * T + 16 * g + q;
+      a0 = MFMA64(vrow[0], X[16 * T + q], a0);
+      a1 = MFMA64(vrow[4], X[16 * T + 4 + q], a1);
+      a2 = MFMA64(vrow[8], X[16 * T + 8 + q], a2);
+      a3 = MFMA64(vrow[12], X[16 * T + 12 + q], a3);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keep the LDS operand loads of later super-tiles from being hoisted
+  }
+  const double4_t acc = t0v + ((a0 + a1) + (a2 + a3)) * sc;  // G = T0 + (X raw^T) diag(scl)
+  double4_t w4 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) w4 = MFMA64(Tfp[(4 * kk + g) * kNB + r], acc[kk], w4);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) Tout[g + 4 * q] = out_scale * (t0v[q] - w4[q]);
+  w4 = w4 * sc;  // the update below multiplies by the unscaled rows
+  const int coff = 16 * (r & 3) + (r >> 2);
+#pragma unroll
+  for (int T = 0; T < DT / 4; ++T) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      double4_t c4 = {X[16 * T + 4 * j], X[16 * T + 4 * j + 1], X[16 * T + 4 * j + 2], X[16 * T + 4 * j + 3]};
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) c4 = MFMA64(-Vp[(4 * kk + g) * LDV + 64 * T + 4 * j + coff], w4[kk], c4);
+      X[16 * T + 4 * j] = c4[0];
+      X[16 * T + 4 * j + 1] = c4[1];
+      X[16 * T + 4 * j + 2] = c4[2];
+      X[16 * T + 4 * j + 3] = c4[3];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+}  // namespace pnode

@@ -188,7 +188,8 @@ int pnode_smooth_checkpoint_means(pnode_batch* h, const int32_t* num_filled, dou
 int pnode_last_step_ms(pnode_batch* h, float* ms_out);
 /* Dense model only, A/B testing of the device paths (all of them HIP, none a CPU fallback): 0 = dispatch by shape
  * (fused one-wavefront kernel for (nu+1)*d <= 32, register-resident MFMA kernels, HBM-tiled large-D kernels, generic
- * kernels otherwise), 1 = generic kernels, 2 = large-D kernels (PNODE_EINVAL if the shape is not supported there).
+ * kernels otherwise), 1 = generic kernels, 2 = large-D kernels (PNODE_EINVAL if the shape is not supported there),
+ * 3 = MFMA kernels with the previous two-launch LQ (32-row passes) instead of the one-launch LQ.
  * No environment variable influences the library: the choice is per handle, through this call only. */
 int pnode_set_generic_path(pnode_batch* h, int32_t enabled);
 /* Enables HIP-event timing of attempt_step (all models). Dense model: also record HIP events between the kernels of a step (on the handle's stream) and
@@ -197,6 +198,12 @@ int pnode_set_phase_timing(pnode_batch* h, int32_t enabled);
 int pnode_last_phase_ms(pnode_batch* h, float* ms_out);
 /* Raw stream handle (hipStream_t) for callers that need to order their own work after ours. */
 void* pnode_stream(pnode_batch* h);
+/* Host-only (no GPU needed): the table that tells the one-launch LQ kernel of the MFMA fast path which wavefront holds which
+ * 16-row strip when (csrc/pnode_device.hpp: LqSchedule), for num_strips = D/16 strips and panels_per_pass panels per pass.
+ * Writes the table to out (capacity bytes) and returns its size; PNODE_EINVAL if no table exists for the shape. Lets the
+ * CPU tests check the invariants the kernel relies on (every strip processed once per pass, a strip that becomes a panel
+ * of the next pass stays with the wavefront that will factorise it). */
+int pnode_lq_schedule(int32_t num_strips, int32_t panels_per_pass, int8_t* out, int32_t capacity);
 
 #ifdef __cplusplus
 }
