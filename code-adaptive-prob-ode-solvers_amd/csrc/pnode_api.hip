@@ -999,6 +999,17 @@ int pnode_last_phase_ms(pnode_batch* h, float* ms_out) {
 
 void* pnode_stream(pnode_batch* h) { return h ? (void*)h->stream : nullptr; }
 
+#ifdef PNODE_TIMING_BUILD
+// Diagnostic build only (make timing -> libpnode_hip_timing.so): 64-bit words of trajectory b's S scratch (in-kernel cycle stamps).
+int pnode_debug_read_scratch(pnode_batch* h, int32_t b, int32_t offset_words, int32_t count, uint64_t* out) {
+  if (!h || !out || !h->dense) return fail(PNODE_EINVAL, "bad argument");
+  const size_t D = h->D, d = h->cfg.d;
+  HIP_TRY(hipMemcpy(out, reinterpret_cast<uint64_t*>(h->dn.S + size_t(b) * d * d) + offset_words, size_t(count) * 8,
+                    hipMemcpyDeviceToHost));
+  return PNODE_OK;
+}
+#endif
+
 int pnode_lq_schedule(int32_t num_strips, int32_t panels_per_pass, int8_t* out, int32_t capacity) {
   if (!out || capacity < int32_t(sizeof(LqSchedule))) return fail(PNODE_EINVAL, "buffer too small for the schedule table");
   LqSchedule S;

@@ -130,10 +130,26 @@ __device__ __forceinline__ void upd16(double& x0, double& x1, double& x2, double
       : "v"(nws), "i"(C));
 }
 
+// Sum of a value over the four 16-lane DPP rows of the wavefront (the four column groups of the strip layout); every lane
+// receives the total, formed in the same order. v_permlane16_swap exchanges rows 1 <-> 0 and 3 <-> 2 between its two operands,
+// v_permlane32_swap the upper half of one with the lower half of the other (gfx950).
+__device__ __forceinline__ double sum_over_groups(double v) {
+  unsigned lo = __double2loint(v), hi = __double2hiint(v);
+  auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  v = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+  lo = __double2loint(v);
+  hi = __double2hiint(v);
+  auto c = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  auto e = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double(e[0], c[0]) + __hiloint2double(e[1], c[1]);
+}
+
+// acc += tfrow[M] * u(lane M of the row), M = 0 .. C-1: one DPP-operand FMA per term
 template <int M, int C>
 __device__ __forceinline__ void tf_accumulate(double& acc, double u, const double (&tfrow)[kNB]) {
   if constexpr (M < C) {
-    acc = fma(tfrow[M], bcast16<M>(u), acc);
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(u), "v"(tfrow[M]), "i"(M));
     tf_accumulate<M + 1, C>(acc, u, tfrow);
   }
 }
@@ -153,10 +169,7 @@ __device__ __forceinline__ void pivot_step(double (&X)[4 * DT], double (&tfrow)[
     dot16<C>(a0, a1, a2, a3, X[e], X[e + 1], X[e + 2], X[e + 3], X[e + 4], X[e + 5], X[e + 6], X[e + 7], X[e + 8], X[e + 9],
              X[e + 10], X[e + 11], X[e + 12], X[e + 13], X[e + 14], X[e + 15]);
   const double part = (a0 + a1) + (a2 + a3);
-  // sum over the four column groups: D[i][j] = sum_k 1 * part(lane (j, k)) -> every lane of row r holds x_r . x_C
-  const double4_t z4 = {0.0, 0.0, 0.0, 0.0};
-  const double4_t d4 = MFMA64(1.0, part, z4);
-  const double dotv = d4[0];
+  const double dotv = sum_over_groups(part);  // every lane of row r holds x_r . x_C
   const double xx = bcast16<C>(dotv);  // |x_C|^2
   double tauc = 0.0, scale = 0.0, beta = alpha;
   {
@@ -179,6 +192,9 @@ __device__ __forceinline__ void pivot_step(double (&X)[4 * DT], double (&tfrow)[
     tfrow[C] = (r < C) ? -tauc * acc : ((r == C) ? tauc : 0.0);
   }
   myscl = (r == C) ? scale : myscl;
+  // pin the recurrence inside its pivot: without this the scheduler sinks all 120 broadcasts below the last asm block of the
+  // sweep (they only feed the publication), spilling their operands on the way
+  asm volatile("" : "+v"(tfrow[C]), "+v"(myscl));
 #pragma unroll
   for (int e = 0; e < 4 * DT; e += 16)
     upd16<C>(X[e], X[e + 1], X[e + 2], X[e + 3], X[e + 4], X[e + 5], X[e + 6], X[e + 7], X[e + 8], X[e + 9], X[e + 10], X[e + 11],
@@ -223,6 +239,7 @@ __global__ __launch_bounds__(64 * kLqWaves) void dense_lq3_mfma_kernel(const Lq3
   __shared__ double TppS[NP * kNB * kNB];  // diagonal blocks of T, staged for a coalesced write
   __shared__ double coef[kMaxN * kMaxN];
   __shared__ double pS[kMaxN];
+  __shared__ int pubS[NP];  // pubS[k] = P + 1 once panel k of pass P is published (V, Tf, scl in LDS); monotone over the passes
 
   const int b = blockIdx.x;
   const StepArg sarg = args[b];
@@ -244,8 +261,17 @@ __global__ __launch_bounds__(64 * kLqWaves) void dense_lq3_mfma_kernel(const Lq3
     for (int i = 0; i < nn; ++i)
       for (int k = 0; k < nn; ++k) coef[i * kMaxN + k] = (k >= i) ? K.a[i][k] * pil[k] : 0.0;
     for (int i = 0; i < kMaxN; ++i) pS[i] = (i < nn) ? pl[i] : 0.0;
+    for (int k = 0; k < NP; ++k) pubS[k] = 0;
   }
   __syncthreads();
+  // Publication flags instead of workgroup barriers inside a pass: a wavefront waits only for the panel it is about to apply,
+  // so the loads of the other wavefronts, their applications and the chain of the four sweeps run decoupled. (LDS operations of
+  // one wavefront complete in order; the release fence drains them before the flag store.)
+  auto wait_published = [&](int k, int P) {
+    volatile int* f = pubS + k;
+    while (__builtin_amdgcn_readfirstlane(*f) < P + 1) __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  };
 
   auto t0_tile = [&](int row0, int col0) {
     // T0[row0 + r][col0 + g + 4q] = sigma chol(Qbar)[ib][jb] where the intra-block indices agree
@@ -259,48 +285,66 @@ __global__ __launch_bounds__(64 * kLqWaves) void dense_lq3_mfma_kernel(const Lq3
   auto load_strip = [&](int st, double (&X)[4 * DT], bool from_state) {
     const int j0 = kNB * st;
     if (from_state) {
+      // Mt rows of derivative block ib: sum_{k >= ib} coef[ib][k] L[k d + q]: one round trip to memory per 64-column group and
+      // k, eight 16-byte loads per lane in flight (a larger staging buffer does not fit next to the 128-register strip).
       const int ib = j0 / d, q = (j0 + r) % d;
 #pragma unroll
-      for (int T4 = 0; T4 < DT / 4; ++T4) {
+      for (int e = 0; e < 4 * DT; ++e) X[e] = 0.0;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) X[16 * T4 + e] = 0.0;
+      for (int T4 = 0; T4 < DT / 4; ++T4) {
 #pragma unroll 1
         for (int k = ib; k < nn; ++k) {
           const double ck = coef[ib * kMaxN + k];
           const double* __restrict__ lrow = Lsrc + size_t(k * d + q) * D + 16 * g + 64 * T4;
+          double2 tmp[8];
 #pragma unroll
-          for (int e = 0; e < 16; e += 2) {
-            const double2 t2 = *reinterpret_cast<const double2*>(lrow + e);
-            X[16 * T4 + e] = fma(ck, t2.x, X[16 * T4 + e]);
-            X[16 * T4 + e + 1] = fma(ck, t2.y, X[16 * T4 + e + 1]);
+          for (int e = 0; e < 8; ++e) tmp[e] = *reinterpret_cast<const double2*>(lrow + 2 * e);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            X[16 * T4 + 2 * e] = fma(ck, tmp[e].x, X[16 * T4 + 2 * e]);
+            X[16 * T4 + 2 * e + 1] = fma(ck, tmp[e].y, X[16 * T4 + 2 * e + 1]);
           }
         }
       }
     } else {
-      const double* __restrict__ rowp = Mt + size_t(j0 + r) * D + 16 * g;
+      // Mt (scratch private to the LQ) lives in the register order of the strips: pair pp of lane l of strip st at
+      // ((st * 2 DT + pp) * 64 + l) * 16 bytes, so every load / store instruction of a wavefront covers 1 KB of contiguous
+      // memory (a row-major strip makes each lane touch a cache line of its own and the address unit serialises them)
+      const double2* __restrict__ src = reinterpret_cast<const double2*>(Mt) + size_t(st) * (2 * DT) * 64 + lane;
 #pragma unroll
-      for (int T4 = 0; T4 < DT / 4; ++T4)
-#pragma unroll
-        for (int e = 0; e < 16; e += 2) {
-          const double2 t2 = *reinterpret_cast<const double2*>(rowp + 64 * T4 + e);
-          X[16 * T4 + e] = t2.x;
-          X[16 * T4 + e + 1] = t2.y;
-        }
+      for (int pp = 0; pp < 2 * DT; ++pp) {
+        const double2 t2 = src[pp * 64];
+        X[2 * pp] = t2.x;
+        X[2 * pp + 1] = t2.y;
+      }
     }
   };
   auto store_strip = [&](int st, const double (&X)[4 * DT]) {
-    double* __restrict__ rowp = Mt + size_t(kNB * st + r) * D + 16 * g;
+    double2* __restrict__ dst = reinterpret_cast<double2*>(Mt) + size_t(st) * (2 * DT) * 64 + lane;
 #pragma unroll
-    for (int T4 = 0; T4 < DT / 4; ++T4)
-#pragma unroll
-      for (int e = 0; e < 16; e += 2) {
-        double2 t2;
-        t2.x = X[16 * T4 + e];
-        t2.y = X[16 * T4 + e + 1];
-        *reinterpret_cast<double2*>(rowp + 64 * T4 + e) = t2;
-      }
+    for (int pp = 0; pp < 2 * DT; ++pp) {
+      double2 t2;
+      t2.x = X[2 * pp];
+      t2.y = X[2 * pp + 1];
+      dst[pp * 64] = t2;
+    }
   };
 
+#ifdef PNODE_TIMING_BUILD
+  // separate diagnostic build only (make timing): per-wavefront cycle sums by phase, written to the S scratch (unused by the MFMA path)
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#define LQ_STAMP(slot)                                              \
+  do {                                                              \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();   \
+    tacc[slot] += now_ - tprev;                                     \
+    tprev = now_;                                                   \
+  } while (0)
+#else
+#define LQ_STAMP(slot) \
+  do {                 \
+  } while (0)
+#endif
   double X[4 * DT];
   bool have = false;
   int mystrip = -1;
@@ -313,6 +357,7 @@ __global__ __launch_bounds__(64 * kLqWaves) void dense_lq3_mfma_kernel(const Lq3
     const bool direct = c0 >= 2 * d;
     auto carried = [&](int s) { return P + 1 < npass && s >= NP * (P + 1) && s < NP * (P + 2); };
     auto apply = [&](int k, int st, double (&Xs)[4 * DT]) {
+      wait_published(k, P);
       const int j0 = kNB * st, cp = c0 + kNB * k;
       double* Trow = (direct ? Ldst : T) + size_t(j0 + r) * D + cp;
       const double osc = direct ? pS[(j0 + r) / d] : 1.0;
@@ -341,9 +386,11 @@ __global__ __launch_bounds__(64 * kLqWaves) void dense_lq3_mfma_kernel(const Lq3
             have = true;
           }
         }
+        LQ_STAMP(0);
 #pragma unroll 1
         for (int k = 0; k < NP; ++k) {
           if (have && k > 0) apply(k - 1, mystrip, X);
+          LQ_STAMP(1);
           if (k == mypanel) {
             // ---- factorise my strip in place and publish it as panel k
             const int cp = c0 + kNB * k;
@@ -355,6 +402,7 @@ __global__ __launch_bounds__(64 * kLqWaves) void dense_lq3_mfma_kernel(const Lq3
             __builtin_amdgcn_s_setprio(3);
             pivot_sweep<0, DT>(X, tfrow, tpp_row, myscl, alpha, r);
             __builtin_amdgcn_s_setprio(0);
+            LQ_STAMP(2);
             double* Vp = Vx + k * kNB * LDV;
 #pragma unroll
             for (int T4 = 0; T4 < DT / 4; ++T4)
@@ -383,8 +431,10 @@ __global__ __launch_bounds__(64 * kLqWaves) void dense_lq3_mfma_kernel(const Lq3
               }
             }
             have = false;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) pubS[k] = P + 1;
+            LQ_STAMP(3);
           }
-          __syncthreads();
         }
       } else {
         const int s = S->round[P][task - 1][wv];
@@ -393,20 +443,30 @@ __global__ __launch_bounds__(64 * kLqWaves) void dense_lq3_mfma_kernel(const Lq3
           load_strip(s, X, P == 0);
           have = true;
         }
+        LQ_STAMP(0);
       }
       if (have) {
         // the panels not applied yet: the last one for the strip held during the chain, all of them otherwise
 #pragma unroll 1
         for (int k = (task == 0) ? NP - 1 : 0; k < NP; ++k) apply(k, mystrip, X);
+        LQ_STAMP(5);
         if (!carried(mystrip)) {
           store_strip(mystrip, X);
           have = false;
         }
+        LQ_STAMP(6);
       }
       // (a carried strip stays: its wavefront is a panel wavefront of the next pass and takes no further task in this one)
     }
     __syncthreads();  // every wavefront is done with this pass's reflectors before the next pass overwrites them
+    LQ_STAMP(7);
   }
+#ifdef PNODE_TIMING_BUILD
+  if (lane == 0) {
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(v.S + size_t(b) * d * d) + wv * 8;
+    for (int i = 0; i < 8; ++i) dbg[i] = tacc[i];
+  }
+#endif
 }
 
 template <int DT, int NP, int DD>

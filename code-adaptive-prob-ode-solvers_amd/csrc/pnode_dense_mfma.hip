@@ -232,13 +232,29 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
             tmp[e] = fma(coef[ib * kMaxN + k], lv[e], tmp[e]);  // coef is zero below the diagonal (k < ib)
           }
         }
-      } else
+      }
+      if constexpr (fused) {
 #pragma unroll
-      for (int e = 0; e < NL; ++e) tmp[e] = Mt[size_t(c0) * D + tid + 256 * e];
+        for (int e = 0; e < NL; ++e) {
+          const int idx = tid + 256 * e;
+          Vx[(idx / D) * LDV + idx % D] = tmp[e];
+        }
+      } else {
+        // Mt is kept in the register order of the strips (mt_pair below): pair p of lane (r, g) of strip s holds
+        // M[16 s + r][64 (p / 8) + 16 g + 2 (p % 8) .. + 1]
+        constexpr int NL2 = NL / 2;
+        double2 t2[NL2];
+        const double2* __restrict__ src = reinterpret_cast<const double2*>(Mt) + size_t(c0 / kNB) * (2 * DT) * 64;
 #pragma unroll
-      for (int e = 0; e < NL; ++e) {
-        const int idx = tid + 256 * e;
-        Vx[(idx / D) * LDV + idx % D] = tmp[e];
+        for (int e = 0; e < NL2; ++e) t2[e] = src[tid + 256 * e];
+#pragma unroll
+        for (int e = 0; e < NL2; ++e) {
+          const int idx = tid + 256 * e;
+          const int sl = idx / (2 * DT * 64), rem = idx % (2 * DT * 64), pp = rem / 64, ln = rem % 64;
+          const int col = 64 * (pp / 8) + 16 * (ln >> 4) + 2 * (pp % 8);
+          Vx[(kNB * sl + (ln & 15)) * LDV + col] = t2[e].x;
+          Vx[(kNB * sl + (ln & 15)) * LDV + col + 1] = t2[e].y;
+        }
       }
     }
     __syncthreads();
@@ -313,9 +329,11 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
     }
     // ---- trailing strips: both panels in one pass over the rows
     const int nstrips = DT - 2 * (P + 1);
+    // Mt (scratch private to the LQ) is stored in the register order of the strips: every load / store instruction of a
+    // wavefront covers 1 KB of contiguous memory (a row-major strip makes each lane touch a cache line of its own)
+    auto mt_pair = [&](int j0, int pp) { return reinterpret_cast<double2*>(Mt) + (size_t(j0 / kNB) * (2 * DT) + pp) * 64 + lane; };
     auto load_strip = [&](int st, double (&X)[4 * DT]) {
       const int j0 = c0 + 2 * kNB + kNB * st;
-      const double* __restrict__ rowp = Mt + size_t(j0 + r) * D + 16 * g;
       if constexpr (fused) {
         const int ib = j0 / d, q = (j0 + r) % d;
 #pragma unroll
@@ -336,13 +354,11 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
         }
       } else
 #pragma unroll
-      for (int T4 = 0; T4 < DT / 4; ++T4)
-#pragma unroll
-        for (int e = 0; e < 16; e += 2) {
-          const double2 t2 = *reinterpret_cast<const double2*>(rowp + 64 * T4 + e);
-          X[16 * T4 + e] = t2.x;
-          X[16 * T4 + e + 1] = t2.y;
-        }
+      for (int pp = 0; pp < 2 * DT; ++pp) {
+        const double2 t2 = *mt_pair(j0, pp);
+        X[2 * pp] = t2.x;
+        X[2 * pp + 1] = t2.y;
+      }
     };
     auto apply_both = [&](int st, double (&X)[4 * DT]) {
       const int j0 = c0 + 2 * kNB + kNB * st;
@@ -353,16 +369,13 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
     };
     auto store_strip = [&](int st, const double (&X)[4 * DT]) {
       const int j0 = c0 + 2 * kNB + kNB * st;
-      double* __restrict__ rowp = Mt + size_t(j0 + r) * D + 16 * g;
 #pragma unroll
-      for (int T4 = 0; T4 < DT / 4; ++T4)
-#pragma unroll
-        for (int e = 0; e < 16; e += 2) {
-          double2 t2;
-          t2.x = X[16 * T4 + e];
-          t2.y = X[16 * T4 + e + 1];
-          *reinterpret_cast<double2*>(rowp + 64 * T4 + e) = t2;
-        }
+      for (int pp = 0; pp < 2 * DT; ++pp) {
+        double2 t2;
+        t2.x = X[2 * pp];
+        t2.y = X[2 * pp + 1];
+        *mt_pair(j0, pp) = t2;
+      }
     };
     // Strips 0 and 1 are the panels of the NEXT pass: wavefronts 0 and 1 process them last, keep them in registers
     // over the end-of-pass barrier and drop them straight into Vx, instead of a write to and a re-read from HBM.
