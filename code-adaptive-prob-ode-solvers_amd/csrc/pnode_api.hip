@@ -135,6 +135,7 @@ struct pnode_batch {
   std::vector<int64_t> steps;
   std::vector<uint8_t> pending;
   bool initialised = false;
+  bool stepped = false;  // a step has run since set_initial: the layout of the state factor is fixed by the path that wrote it
   std::vector<void*> allocations;
 };
 
@@ -404,6 +405,7 @@ int pnode_set_initial(pnode_batch* h, const double* tcoeffs, const double* t0, c
     h->pending[b] = 0;
   }
   h->initialised = true;
+  h->stepped = false;
   return PNODE_OK;
 }
 
@@ -420,6 +422,7 @@ int pnode_set_tolerances(pnode_batch* h, const double* atol, const double* rtol)
 }
 
 static void enqueue_step(pnode_batch* h, const StepArg* dargs) {
+  h->stepped = true;
   if (h->dense)
     dense_launch_step(h->dn, dargs, h->dK, h->stream, h->phase_timing ? &h->phase : nullptr);
   else
@@ -920,7 +923,14 @@ int pnode_read_factor(pnode_batch* h, int32_t which, double* out) {
   for (size_t b = 0; b < B; ++b) {
     HIP_TRY(hipMemcpy(tmp.data(), base + (size_t(slot_of(h, which, b)) * B + b) * m * m, m * m * sizeof(double),
                       hipMemcpyDeviceToHost));
-    if (h->dense) {  // stored as L (Sigma = L L^T): hand out R = L^T
+    if (h->dense && dense_state_factor_tiled(h->dn)) {  // L in the register order of the 16-row strips: de-tile, hand out R = L^T
+      const size_t DT = m / 16;
+      for (size_t i = 0; i < m; ++i)      // row of L
+        for (size_t j = 0; j < m; ++j) {  // column of L
+          const size_t s = i >> 4, r = i & 15, T = j >> 6, g = (j >> 4) & 3, e = j & 15;
+          out[b * m * m + j * m + i] = tmp[((s * 2 * DT + 8 * T + (e >> 1)) * 64 + r + 16 * g) * 2 + (e & 1)];
+        }
+    } else if (h->dense) {  // stored as L (Sigma = L L^T): hand out R = L^T
       for (size_t i = 0; i < m; ++i)
         for (size_t j = 0; j < m; ++j) out[b * m * m + i * m + j] = tmp[j * m + i];
     } else {
@@ -976,10 +986,12 @@ int pnode_last_step_ms(pnode_batch* h, float* ms_out) {
 int pnode_set_generic_path(pnode_batch* h, int32_t enabled) {
   if (!h) return fail(PNODE_EINVAL, "null handle");
   if (enabled == 2 && !dense_large_supported(h->dn)) return fail(PNODE_EINVAL, "the large-D path does not support this shape");
+  if (h->stepped)
+    return fail(PNODE_ESTATE, "the device path is chosen before the first step (the paths store the state factor in different layouts)");
   h->dn.force_generic = enabled == 1 || h->dn.fixedpoint;  // the register-resident MFMA kernels have no extra-row LQ
   h->dn.user_generic = enabled == 1;
   h->dn.force_large = enabled == 2;
-  h->dn.lq_legacy = enabled == 3;
+  h->dn.lq_one_launch = enabled == 3;
   return PNODE_OK;
 }
 

@@ -366,6 +366,14 @@ __global__ __launch_bounds__(kThreads) void dense_interp_kernel(DenseView v, con
   if (threadIdx.x == 0) v.ck_steps[size_t(b) * v.K + arg.ckpt] = arg.steps;
 }
 
+// The handles whose steps run on the register-resident MFMA kernels keep the state factor in the register order of the
+// 16-row strips (pnode_mfma_common.hpp); every other path stores L row-major. Same predicate as the dispatch below.
+bool dense_state_factor_tiled(const DenseView& v) {
+  if (dense_small_supported(v) && !v.force_generic) return false;
+  if (dense_use_large(v)) return false;
+  return dense_mfma_supported(v) && !v.force_generic;
+}
+
 void dense_launch_step(const DenseView& v, const StepArg* args, const IwpConst* K, hipStream_t s,
                        const PhaseEvents* ev) {
   auto mark = [&](int i) {

@@ -287,7 +287,7 @@ __global__ __launch_bounds__(64 * kLqWaves) void dense_lq3_mfma_kernel(const Lq3
     if (from_state) {
       // Mt rows of derivative block ib: sum_{k >= ib} coef[ib][k] L[k d + q]: one round trip to memory per 64-column group and
       // k, eight 16-byte loads per lane in flight (a larger staging buffer does not fit next to the 128-register strip).
-      const int ib = j0 / d, q = (j0 + r) % d;
+      const int ib = j0 / d;
 #pragma unroll
       for (int e = 0; e < 4 * DT; ++e) X[e] = 0.0;
 #pragma unroll
@@ -295,10 +295,11 @@ __global__ __launch_bounds__(64 * kLqWaves) void dense_lq3_mfma_kernel(const Lq3
 #pragma unroll 1
         for (int k = ib; k < nn; ++k) {
           const double ck = coef[ib * kMaxN + k];
-          const double* __restrict__ lrow = Lsrc + size_t(k * d + q) * D + 16 * g + 64 * T4;
+          // (rows k d + q of the state factor form whole strips, stored in register order: coalesced 1 KB per instruction)
+          const double2* __restrict__ lrow = reinterpret_cast<const double2*>(Lsrc) + (size_t((k * d + j0 % d) / kNB) * (2 * DT) + 8 * T4) * 64 + lane;
           double2 tmp[8];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) tmp[e] = *reinterpret_cast<const double2*>(lrow + 2 * e);
+          for (int e = 0; e < 8; ++e) tmp[e] = lrow[e * 64];
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             X[16 * T4 + 2 * e] = fma(ck, tmp[e].x, X[16 * T4 + 2 * e]);
@@ -359,9 +360,17 @@ __global__ __launch_bounds__(64 * kLqWaves) void dense_lq3_mfma_kernel(const Lq3
     auto apply = [&](int k, int st, double (&Xs)[4 * DT]) {
       wait_published(k, P);
       const int j0 = kNB * st, cp = c0 + kNB * k;
-      double* Trow = (direct ? Ldst : T) + size_t(j0 + r) * D + cp;
-      const double osc = direct ? pS[(j0 + r) / d] : 1.0;
-      apply_panel_to_strip<DT, LDV>(Xs, Vx + k * kNB * LDV, TfS + k * kNB * kNB, sclS + k * kNB, t0_tile(j0, cp), Trow, osc, r, g);
+      double4_t tv;
+      apply_panel_to_strip<DT, LDV>(Xs, Vx + k * kNB * LDV, TfS + k * kNB * kNB, sclS + k * kNB, t0_tile(j0, cp), tv, r, g);
+      if (direct) {
+        const double osc = pS[(j0 + r) / d];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Ldst[tiled_index<DT>(j0 + r, cp + g + 4 * q)] = osc * tv[q];
+      } else {
+        double* Trow = T + size_t(j0 + r) * D + cp;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Trow[g + 4 * q] = tv[q];
+      }
     };
     int mypanel = -1;
 #pragma unroll
@@ -420,14 +429,14 @@ __global__ __launch_bounds__(64 * kLqWaves) void dense_lq3_mfma_kernel(const Lq3
 #pragma unroll
               for (int q = 0; q < 4; ++q) o4[q] = tpp_row[4 * g + q];
               const int row = cp + r;
-              double* dstp = (direct ? Ldst : T) + size_t(row) * D + cp + 4 * g;
               const double osc = direct ? pS[row / d] : 1.0;
 #pragma unroll
               for (int q = 0; q < 4; q += 2) {
                 double2 t2;
                 t2.x = osc * o4[q];
                 t2.y = osc * o4[q + 1];
-                *reinterpret_cast<double2*>(dstp + q) = t2;
+                double* dstp = direct ? Ldst + tiled_index<DT>(row, cp + 4 * g + q) : T + size_t(row) * D + cp + 4 * g + q;
+                *reinterpret_cast<double2*>(dstp) = t2;  // (4 g + q is even: the pair is contiguous in both layouts)
               }
             }
             have = false;

@@ -210,51 +210,39 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
     const int c0 = 2 * kNB * P;
     const bool direct = c0 >= 2 * d;  // (2d is a multiple of 32: a pass is either all below or all beyond)
     if (!carried) {
-      constexpr int NL = 2 * kNB * D / 256;
-      double tmp[NL];
+      // the 32 rows of the pass's two panels, read in the register order of their strips (coalesced) and scattered into Vx:
+      // pair pp of lane ln of strip sl holds M[16 sl + (ln & 15)][64 (pp / 8) + 16 (ln >> 4) + 2 (pp % 8) .. + 1]
+      constexpr int NL2 = 2 * kNB * D / 512;
+      double2 t2[NL2];
       if constexpr (fused) {
-        // k outermost: the NL loads of one k are all in flight together (an e-outer loop exposes one memory latency
-        // per element and k)
+        // pass 0: rows 0 .. 31 lie in derivative block 0 (d >= 32): Mt = sum_k coef[0][k] L[k d + row]; k outermost, so the
+        // loads of one k are all in flight together
 #pragma unroll
-        for (int e = 0; e < NL; ++e) tmp[e] = 0.0;
+        for (int e = 0; e < NL2; ++e) t2[e].x = t2[e].y = 0.0;
         for (int k = 0; k < nn; ++k) {
-          double lv[NL];
+          const double2* __restrict__ src = reinterpret_cast<const double2*>(Lsrc) + size_t(k * d / kNB) * (2 * DT) * 64;
+          const double ck = coef[k];
+          double2 lv[NL2];
 #pragma unroll
-          for (int e = 0; e < NL; ++e) {
-            const int idx = tid + 256 * e;
-            const int row = idx / D, cidx = idx % D;  // rows 0..31 lie in derivative block 0 or (d == 16) 0 and 1
-            const int ib = row / d, q = row % d;
-            lv[e] = (k >= ib) ? Lsrc[size_t(k * d + q) * D + cidx] : 0.0;
+          for (int e = 0; e < NL2; ++e) lv[e] = src[tid + 256 * e];
+#pragma unroll
+          for (int e = 0; e < NL2; ++e) {
+            t2[e].x = fma(ck, lv[e].x, t2[e].x);
+            t2[e].y = fma(ck, lv[e].y, t2[e].y);
           }
-#pragma unroll
-          for (int e = 0; e < NL; ++e) {
-            const int ib = ((tid + 256 * e) / D) / d;
-            tmp[e] = fma(coef[ib * kMaxN + k], lv[e], tmp[e]);  // coef is zero below the diagonal (k < ib)
-          }
-        }
-      }
-      if constexpr (fused) {
-#pragma unroll
-        for (int e = 0; e < NL; ++e) {
-          const int idx = tid + 256 * e;
-          Vx[(idx / D) * LDV + idx % D] = tmp[e];
         }
       } else {
-        // Mt is kept in the register order of the strips (mt_pair below): pair p of lane (r, g) of strip s holds
-        // M[16 s + r][64 (p / 8) + 16 g + 2 (p % 8) .. + 1]
-        constexpr int NL2 = NL / 2;
-        double2 t2[NL2];
         const double2* __restrict__ src = reinterpret_cast<const double2*>(Mt) + size_t(c0 / kNB) * (2 * DT) * 64;
 #pragma unroll
         for (int e = 0; e < NL2; ++e) t2[e] = src[tid + 256 * e];
+      }
 #pragma unroll
-        for (int e = 0; e < NL2; ++e) {
-          const int idx = tid + 256 * e;
-          const int sl = idx / (2 * DT * 64), rem = idx % (2 * DT * 64), pp = rem / 64, ln = rem % 64;
-          const int col = 64 * (pp / 8) + 16 * (ln >> 4) + 2 * (pp % 8);
-          Vx[(kNB * sl + (ln & 15)) * LDV + col] = t2[e].x;
-          Vx[(kNB * sl + (ln & 15)) * LDV + col + 1] = t2[e].y;
-        }
+      for (int e = 0; e < NL2; ++e) {
+        const int idx = tid + 256 * e;
+        const int sl = idx / (2 * DT * 64), rem = idx % (2 * DT * 64), pp = rem / 64, ln = rem % 64;
+        const int col = 64 * (pp / 8) + 16 * (ln >> 4) + 2 * (pp % 8);
+        Vx[(kNB * sl + (ln & 15)) * LDV + col] = t2[e].x;
+        Vx[(kNB * sl + (ln & 15)) * LDV + col + 1] = t2[e].y;
       }
     }
     __syncthreads();
@@ -293,9 +281,9 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
       if (wv == 0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const size_t o = size_t(c0 + kNB + r) * D + c0 + g + 4 * q;
-          if (direct) Ldst[o] = pS[(c0 + kNB + r) / d] * (t0v[q] - w4[q]);
-          else T[o] = t0v[q] - w4[q];
+          const int row = c0 + kNB + r, col = c0 + g + 4 * q;
+          if (direct) Ldst[tiled_index<DT>(row, col)] = pS[row / d] * (t0v[q] - w4[q]);
+          else T[size_t(row) * D + col] = t0v[q] - w4[q];
         }
       }
       w4 = w4 * sc;
@@ -319,8 +307,8 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
       if (j <= i) {
         const size_t oa = size_t(c0 + i) * D + c0 + j, ob = size_t(c0 + kNB + i) * D + c0 + kNB + j;
         if (direct) {
-          Ldst[oa] = pS[(c0 + i) / d] * psA.Tpp[i * kNB + j];
-          Ldst[ob] = pS[(c0 + kNB + i) / d] * psB.Tpp[i * kNB + j];
+          Ldst[tiled_index<DT>(c0 + i, c0 + j)] = pS[(c0 + i) / d] * psA.Tpp[i * kNB + j];
+          Ldst[tiled_index<DT>(c0 + kNB + i, c0 + kNB + j)] = pS[(c0 + kNB + i) / d] * psB.Tpp[i * kNB + j];
         } else {
           T[oa] = psA.Tpp[i * kNB + j];
           T[ob] = psB.Tpp[i * kNB + j];
@@ -335,7 +323,7 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
     auto load_strip = [&](int st, double (&X)[4 * DT]) {
       const int j0 = c0 + 2 * kNB + kNB * st;
       if constexpr (fused) {
-        const int ib = j0 / d, q = (j0 + r) % d;
+        const int ib = j0 / d;
 #pragma unroll
         for (int T4 = 0; T4 < DT / 4; ++T4) {
 #pragma unroll
@@ -343,10 +331,11 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
 #pragma unroll 1
           for (int k = ib; k < nn; ++k) {
             const double ck = coef[ib * kMaxN + k];
-            const double* __restrict__ lrow = Lsrc + size_t(k * d + q) * D + 16 * g + 64 * T4;
+            // (rows k d + q of the state factor form whole strips: 16 | d)
+            const double2* __restrict__ lrow = reinterpret_cast<const double2*>(Lsrc) + (size_t((k * d + j0 % d) / kNB) * (2 * DT) + 8 * T4) * 64 + lane;
 #pragma unroll
             for (int e = 0; e < 16; e += 2) {
-              const double2 t2 = *reinterpret_cast<const double2*>(lrow + e);
+              const double2 t2 = lrow[(e / 2) * 64];
               X[16 * T4 + e] = fma(ck, t2.x, X[16 * T4 + e]);
               X[16 * T4 + e + 1] = fma(ck, t2.y, X[16 * T4 + e + 1]);
             }
@@ -362,10 +351,24 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
     };
     auto apply_both = [&](int st, double (&X)[4 * DT]) {
       const int j0 = c0 + 2 * kNB + kNB * st;
-      double* Trow = (direct ? Ldst : T) + size_t(j0 + r) * D + c0;
-      const double osc = direct ? pS[(j0 + r) / d] : 1.0;
-      apply_panel_to_strip<DT, LDV>(X, VA, psA.Tf, psA.scl, t0_tile(j0, c0), Trow, osc, r, g);
-      apply_panel_to_strip<DT, LDV>(X, VB, psB.Tf, psB.scl, t0_tile(j0, c0 + kNB), Trow + kNB, osc, r, g);
+      double4_t ta, tb;
+      apply_panel_to_strip<DT, LDV>(X, VA, psA.Tf, psA.scl, t0_tile(j0, c0), ta, r, g);
+      apply_panel_to_strip<DT, LDV>(X, VB, psB.Tf, psB.scl, t0_tile(j0, c0 + kNB), tb, r, g);
+      if (direct) {
+        const double osc = pS[(j0 + r) / d];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          Ldst[tiled_index<DT>(j0 + r, c0 + g + 4 * q)] = osc * ta[q];
+          Ldst[tiled_index<DT>(j0 + r, c0 + kNB + g + 4 * q)] = osc * tb[q];
+        }
+      } else {
+        double* Trow = T + size_t(j0 + r) * D + c0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          Trow[g + 4 * q] = ta[q];
+          Trow[kNB + g + 4 * q] = tb[q];
+        }
+      }
     };
     auto store_strip = [&](int st, const double (&X)[4 * DT]) {
       const int j0 = c0 + 2 * kNB + kNB * st;
@@ -836,7 +839,8 @@ __global__ __launch_bounds__(256, 2) void dense_strip_update_mfma_kernel(DenseVi
       __builtin_amdgcn_sched_barrier(0);
     }
     {
-      double* __restrict__ lrow = Ln + size_t(row) * D + 16 * g;
+      // the state factor is stored in the register order of the strips (pnode_mfma_common.hpp): 1 KB per store instruction
+      double2* __restrict__ lrow = reinterpret_cast<double2*>(Ln) + size_t(st) * (2 * DT) * 64 + lane;
 #pragma unroll
       for (int T4 = 0; T4 < W2 / 64; ++T4)
 #pragma unroll
@@ -844,7 +848,7 @@ __global__ __launch_bounds__(256, 2) void dense_strip_update_mfma_kernel(DenseVi
           double2 t2;
           t2.x = X[16 * T4 + e];
           t2.y = X[16 * T4 + e + 1];
-          *reinterpret_cast<double2*>(lrow + 64 * T4 + e) = t2;
+          lrow[(8 * T4 + e / 2) * 64] = t2;
         }
     }
     // (columns >= 2d of these rows were written by the LQ kernel, already scaled)
@@ -880,7 +884,7 @@ static void launch_mfma(const DenseView& v, const StepArg* args, const IwpConst*
     if (ev) (void)hipEventRecord(ev->ev[i], s);
   };
   mark(2);
-  if (!v.lq_legacy && dense_lq3_supported(v)) {
+  if (v.lq_one_launch && dense_lq3_supported(v)) {
     dense_launch_lq3(v, args, K, s);  // one launch, 64-row passes, register-resident panels (pnode_dense_lq.hip)
   } else {
     hipLaunchKernelGGL((dense_lq2_mfma_kernel<DT, true>), dim3(v.B), dim3(256), 0, s, v, args, K, 0);

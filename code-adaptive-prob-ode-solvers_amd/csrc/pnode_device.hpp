@@ -38,7 +38,8 @@ struct DenseView {
   int B, d, k, n, D, K;
   int ts1, dynamic, vf_id, P, prm_per_traj;
   int force_generic;  // 1: never take the MFMA fast path (A/B testing)
-  int lq_legacy;      // 1: MFMA fast path with the previous two-launch, 32-row-pass LQ (A/B partner of pnode_dense_lq.hip)
+  int lq_one_launch;  // 1: MFMA fast path with the one-launch, 64-row-pass LQ of pnode_dense_lq.hip (less HBM traffic, faster up to
+                      // one trajectory per CU) instead of the two-launch, 32-row-pass LQ (faster when several trajectories share a CU)
   double* mean;   // [3][B][n][d]
   double* U;      // [3][B][D][D]   Sigma = U^T U (row-major)
   double* sigma;  // [3][B]
@@ -106,6 +107,7 @@ struct PhaseEvents {
 void dense_launch_step(const DenseView& v, const StepArg* args, const IwpConst* K, hipStream_t s,
                        const PhaseEvents* ev = nullptr);
 bool dense_mfma_supported(const DenseView& v);
+bool dense_state_factor_tiled(const DenseView& v);  // L in the register order of the strips (MFMA path) instead of row-major
 void dense_launch_mfma_begin(const DenseView& v, const StepArg* args, const IwpConst* K, hipStream_t s);
 void dense_launch_mfma_tail(const DenseView& v, const StepArg* args, const IwpConst* K, hipStream_t s,
                             const PhaseEvents* ev);

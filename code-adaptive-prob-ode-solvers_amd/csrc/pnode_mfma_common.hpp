@@ -50,12 +50,26 @@ __device__ __forceinline__ double row16_sum(double v) {
   return v;
 }
 
-// One panel's reflectors applied to a register strip X (HBM layout). Writes T[J][P] = T0 - W.
+// ---------------------------------------------------------------------------------------------
+// State factor of the handles that run the register-resident MFMA kernels: L (D x D) is stored in HBM in the REGISTER ORDER
+// of the 16-row strips ("tiled"): lane l = r + 16 g of strip s holds, as its pair pp = 8 T + e / 2, the two elements
+//      L[16 s + r][64 T + 16 g + e], L[16 s + r][64 T + 16 g + e + 1]        (e even)
+// at double2 index (s * 2 DT + pp) * 64 + l. Every load / store instruction of a wavefront then covers 1 KB of contiguous
+// memory; in a row-major strip every lane touches a cache line of its own and the address unit serialises the 64 requests
+// (measured: 2 TB/s against 4.5 TB/s). pnode_read_factor de-tiles on the host.
+// ---------------------------------------------------------------------------------------------
+template <int DT>
+__device__ __forceinline__ size_t tiled_index(int row, int col) {  // element index (in doubles) of L[row][col]
+  const int s = row >> 4, r = row & 15, T = col >> 6, g = (col >> 4) & 3, e = col & 15;
+  return ((size_t(s) * (2 * DT) + 8 * T + (e >> 1)) * 64 + r + 16 * g) * 2 + (e & 1);
+}
+
+// One panel's reflectors applied to a register strip X (HBM layout). Returns T[J][P] = T0 - W in tvals (C/D fragment:
+// lane (r, g) holds columns g + 4 q of row r).
 template <int DT, int LDV>
 __device__ __forceinline__ void apply_panel_to_strip(double (&X)[4 * DT], const double* __restrict__ Vp,
                                                      const double* __restrict__ Tfp, const double* __restrict__ sclp,
-                                                     double4_t t0v, double* __restrict__ Tout, double out_scale, int r,
-                                                     int g) {
+                                                     double4_t t0v, double4_t& tvals, int r, int g) {
   double4_t a0 = {0.0, 0.0, 0.0, 0.0}, a1 = a0, a2 = a0, a3 = a0;
   double4_t sc;
 #pragma unroll
@@ -76,8 +90,7 @@ __device__ __forceinline__ void apply_panel_to_strip(double (&X)[4 * DT], const 
   double4_t w4 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) w4 = MFMA64(Tfp[(4 * kk + g) * kNB + r], acc[kk], w4);
-#pragma unroll
-  for (int q = 0; q < 4; ++q) Tout[g + 4 * q] = out_scale * (t0v[q] - w4[q]);
+  tvals = t0v - w4;
   w4 = w4 * sc;  // the update below multiplies by the unscaled rows
   const int coff = 16 * (r & 3) + (r >> 2);
 #pragma unroll

@@ -63,7 +63,7 @@ class PnodeConfig(C.Structure):
 _lib = None
 
 # A/B testing of the dense device paths through the high-level API: every dense Batch created while this is non-zero
-# calls pnode_set_generic_path with it (1 = generic kernels, 2 = large-D kernels, 3 = previous two-launch LQ).
+# calls pnode_set_generic_path with it (1 = generic kernels, 2 = large-D kernels, 3 = MFMA kernels with the one-launch LQ).
 # Tests set it with monkeypatch.setattr; nothing reads the environment.
 dense_path = 0
 

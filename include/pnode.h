@@ -189,7 +189,9 @@ int pnode_last_step_ms(pnode_batch* h, float* ms_out);
 /* Dense model only, A/B testing of the device paths (all of them HIP, none a CPU fallback): 0 = dispatch by shape
  * (fused one-wavefront kernel for (nu+1)*d <= 32, register-resident MFMA kernels, HBM-tiled large-D kernels, generic
  * kernels otherwise), 1 = generic kernels, 2 = large-D kernels (PNODE_EINVAL if the shape is not supported there),
- * 3 = MFMA kernels with the previous two-launch LQ (32-row passes) instead of the one-launch LQ.
+ * 3 = MFMA kernels with the one-launch LQ (64-row passes, csrc/pnode_dense_lq.hip) instead of the two-launch LQ.
+ * The choice must be made before the first step after pnode_set_initial (PNODE_ESTATE afterwards): the paths keep the state
+ * factor in different layouts.
  * No environment variable influences the library: the choice is per handle, through this call only. */
 int pnode_set_generic_path(pnode_batch* h, int32_t enabled);
 /* Enables HIP-event timing of attempt_step (all models). Dense model: also record HIP events between the kernels of a step (on the handle's stream) and

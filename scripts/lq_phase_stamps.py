@@ -19,6 +19,7 @@ y0 = np.stack([brusselator_y0(N, 0.1 * b) for b in range(B)])
 tc = np.stack(tcoeffs(vf, [y0], nu), axis=1)
 bt = _backend.Batch(batch=B, d=vf.d, nu=nu, ode_order=1, model="dense", correction="ts1", strategy="filter",
                     calibration="dynamic", vf_id=vf.vf_id, vf_params=vf.param_array(), num_checkpoints=2)
+bt.set_generic_path(3)  # the one-launch LQ
 bt.set_initial(tc, np.zeros(B), np.ones(B))
 bt.set_tolerances(1e-6, 1e-6)
 err, one = np.zeros(B), np.ones(B, np.uint8)
