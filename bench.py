@@ -3,8 +3,11 @@
 dynamic calibration, fp64 (BASELINE.json metric).
 
 A "step" of this benchmark is ONE batched attempted solver step: every trajectory of the batch runs
-predict -> linearise -> calibrate -> correct -> error norm on the GPU, then the host PI controller
-accepts/rejects and proposes the next step sizes. Inputs are resident in HBM before the timed region.
+predict -> linearise -> calibrate -> correct -> error norm on the GPU, then the PI controller accepts /
+rejects and proposes the next step sizes -- by default in a controller kernel on the device (SURVEY 8(f)-1,
+`--controller device`: the K timed steps are enqueued back to back and synchronised once), or on the host
+with one round trip per step (`--controller host`, the north star's division of labour; same decisions, see
+tests/test_gpu_round2.py). Inputs are resident in HBM before the timed region.
 `value` = accepted trajectory-steps of all ranks / wall time of the slowest rank.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu-baseline]
@@ -128,6 +131,9 @@ def main():
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="strong: ONE batch of --batch trajectories sharded over the GPUs (BASELINE config 4); weak: --batch per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--controller", default="device", choices=["device", "host"],
+                    help="device: accept/reject + PI law in a controller kernel between the attempts, the timed steps are enqueued "
+                         "back to back with one synchronisation at the end (pnode_advance_device); host: one round trip per step")
     ap.add_argument("--model", default="dense", choices=["dense", "isotropic"])
     ap.add_argument("--diag-fixed-dt", type=float, default=0.0,
                     help="diagnostics only: constant step size, controller bypassed")
@@ -204,21 +210,41 @@ def main():
             loop.steps += 1
 
         loop.attempt = diag_attempt
-    for _ in range(args.warmup):
-        loop.attempt(active)
-    barrier()
-    acc0 = int(loop.steps.sum())
-    loop.device_ms = 0.0
     phase = np.zeros(4)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loop.attempt(active)
+    device_ctl = args.controller == "device" and args.diag_fixed_dt == 0.0
+    if device_ctl:
+        # controller on the device: W warm-up attempts, then EXACTLY K attempts of the whole batch enqueued back to back
+        dt_state, lp_state = np.full(B, DT0), np.zeros(B)
+        never = np.full(B, np.inf)
+        ctl = asolver.control
+        if args.warmup > 0:
+            batch.advance_device(never, dt_state, lp_state, ctl, asolver.numerical_zero, args.warmup)
+        barrier()
+        acc0 = int(batch.read_time()[1].sum())
+        t0 = time.perf_counter()
+        status, attempts = batch.advance_device(never, dt_state, lp_state, ctl, asolver.numerical_zero, args.steps)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        assert np.all(attempts == args.steps), "a trajectory stopped attempting inside the timed region"
+        accepted = int(batch.read_time()[1].sum()) - acc0
+        dev_ms = batch.last_step_ms()  # HIP events around the K attempts on the handle's stream
         if dense:
-            phase += batch.last_phase_ms()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    accepted = int(loop.steps.sum()) - acc0
-    dev_ms = loop.device_ms
+            phase = np.array(batch.last_phase_ms()) * args.steps  # events of the last attempt (every attempt launches the same kernels)
+    else:
+        for _ in range(args.warmup):
+            loop.attempt(active)
+        barrier()
+        acc0 = int(loop.steps.sum())
+        loop.device_ms = 0.0
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loop.attempt(active)
+            if dense:
+                phase += batch.last_phase_ms()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        accepted = int(loop.steps.sum()) - acc0
+        dev_ms = loop.device_ms
 
     if dist is not None:
         import torch
@@ -278,6 +304,8 @@ def main():
                                    + (f", {B} trajectories on rank 0" if world > 1 else ""),
                        "batch_per_gpu": B, "global_batch": total, "parallelism": f"shard{world}",
                        "gather": gather_how if world > 1 else None,
+                       "controller": "device-resident (controller kernel between the attempts, one host synchronisation for the "
+                                     "K timed steps)" if device_ctl else "host (one round trip per step)",
                        "attempted_steps_per_s": total * K / elapsed,
                        "device_ms_per_step": dev_ms / K},
         }

@@ -103,6 +103,63 @@ __global__ void gather_u_kernel(const double* __restrict__ mean, const StepArg* 
   for (int j = threadIdx.x; j < d; j += blockDim.x) out[(size_t(b) * G + g) * d + j] = m[j];
 }
 
+// Device-resident controller, multi-kernel form (a dense attempt is several launches): runs between two attempts, one thread per
+// trajectory. Takes the error norm of the attempt just made (if any), accepts / rejects, applies the PI law, rotates the state
+// slots and writes the arguments of the next attempt to device memory -- same arithmetic and order as the host loop of
+// pnode_solve_adaptive_save_at (control_proportional_integral + adaptive, /root/reference/src/odecheckpts/ivpsolvers.py:52-53).
+__global__ void dense_ctl_kernel(TrajCtl* __restrict__ ctl, StepArg* __restrict__ args, const double* __restrict__ err,
+                                 ControlParams cp, int B, int first) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  TrajCtl c = ctl[b];
+  StepArg a = args[b];
+  if (c.status != 0) {  // < 0: not taking part; 1, 2: done
+    if (a.active) {
+      a.active = 0;
+      args[b] = a;
+    }
+    return;
+  }
+  if (!first && a.active) {
+    const double e = err[b], dt = a.dt;
+    c.attempts += 1;
+    bool accept;
+    if (e != e) {
+      c.status = 2;  // NaN error estimate: stop (the reference accepts the NaN state and fails later)
+      accept = true;
+    } else {
+      const double le = log(e);
+      const double raw = cp.safety * exp(cp.n2 * c.log_prev - (cp.n1 + cp.n2) * le);
+      const double factor = fmax(cp.factor_min, fmin(raw, cp.factor_max));
+      if (e <= 1.0) c.log_prev = le;
+      c.dt = factor * dt;
+      accept = !(e > 1.0);
+    }
+    if (accept) {
+      c.s_if = c.s_sf;
+      c.t_if = c.t_sf;
+      c.s_sf = c.s_pr;
+      c.t_sf += dt;
+      c.steps += 1;
+      int fr = 0;
+      while (fr == c.s_if || fr == c.s_sf) ++fr;
+      c.s_pr = fr;
+    }
+    if (c.status == 0 && !(isfinite(c.dt) && isfinite(c.t_sf) && c.dt > 0.0)) c.status = 2;
+  }
+  if (c.status == 0 && !(c.t_sf + cp.numerical_zero < c.t_stop)) c.status = 1;
+  double dt = c.dt;
+  if (cp.clip) dt = fmin(dt, c.t_stop - c.t_sf);
+  a.active = c.status == 0 ? 1 : 0;
+  a.dt = a.active ? dt : 1.0;
+  a.t = c.t_sf;
+  a.src = c.s_sf;
+  a.dst = c.s_pr;
+  a.pad = 0;
+  args[b] = a;
+  ctl[b] = c;
+}
+
 }  // namespace
 
 struct pnode_batch {
@@ -116,6 +173,7 @@ struct pnode_batch {
   IsoView iso{};
   DenseView dn{};
   IwpConst* dK = nullptr;
+  TrajCtl* dCtl = nullptr;      // device-resident controller state (multi-kernel form)
   StepArg* dArgs = nullptr;
   InterpArg* dIargs = nullptr;
   int32_t* dFilled = nullptr;
@@ -251,6 +309,7 @@ int pnode_create(const pnode_config* cfg, pnode_batch** out) {
 
   ALLOC(h->dK, 1);
   ALLOC(h->dArgs, B);
+  ALLOC(h->dCtl, B);
   ALLOC(h->dIargs, B);
   ALLOC(h->dFilled, B);
   ALLOC(h->dAtol, B);
@@ -421,12 +480,42 @@ int pnode_set_tolerances(pnode_batch* h, const double* atol, const double* rtol)
   return PNODE_OK;
 }
 
-static void enqueue_step(pnode_batch* h, const StepArg* dargs) {
+static void enqueue_step(pnode_batch* h, const StepArg* dargs, double* errnorm = nullptr) {
   h->stepped = true;
-  if (h->dense)
-    dense_launch_step(h->dn, dargs, h->dK, h->stream, h->phase_timing ? &h->phase : nullptr);
-  else
+  if (h->dense) {
+    if (errnorm) {  // error norms to device memory (device-resident controller) instead of the pinned host buffer
+      DenseView v = h->dn;
+      v.errnorm = errnorm;
+      dense_launch_step(v, dargs, h->dK, h->stream, h->phase_timing ? &h->phase : nullptr);
+    } else {
+      dense_launch_step(h->dn, dargs, h->dK, h->stream, h->phase_timing ? &h->phase : nullptr);
+    }
+  } else if (errnorm) {
+    IsoView v = h->iso;
+    v.errnorm = errnorm;
+    iso_launch_step(v, dargs, h->dK, h->stream);
+  } else {
     iso_launch_step(h->iso, dargs, h->dK, h->stream);
+  }
+}
+
+// `rounds` batched attempts enqueued back to back, each followed by the controller kernel; no host synchronisation inside.
+// hCtl[b].status: in 0 = take part, < 0 = skip; out 0 = still running, 1 = reached t_stop, 2 = failed.
+static int advance_rounds_device(pnode_batch* h, TrajCtl* hCtl, const ControlParams& cp, int rounds) {
+  const size_t B = h->cfg.batch;
+  const unsigned blocks = unsigned((B + 255) / 256);
+  HIP_TRY(hipMemcpyAsync(h->dCtl, hCtl, B * sizeof(TrajCtl), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(dense_ctl_kernel, dim3(blocks), dim3(256), 0, h->stream, h->dCtl, h->dArgs, h->dErr, cp, int(B), 1);
+  if (h->step_timing) HIP_TRY(hipEventRecord(h->ev0, h->stream));
+  for (int r = 0; r < rounds; ++r) {
+    enqueue_step(h, h->dArgs, h->dErr);
+    hipLaunchKernelGGL(dense_ctl_kernel, dim3(blocks), dim3(256), 0, h->stream, h->dCtl, h->dArgs, h->dErr, cp, int(B), 0);
+  }
+  if (h->step_timing) HIP_TRY(hipEventRecord(h->ev1, h->stream));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(hCtl, h->dCtl, B * sizeof(TrajCtl), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return PNODE_OK;
 }
 
 int pnode_attempt_step(pnode_batch* h, const double* dt, const uint8_t* active, double* err_norm_out) {
@@ -692,8 +781,10 @@ int pnode_solve_adaptive_save_at_device(pnode_batch* h, const double* save_at, i
   if (!h || !save_at || !dt0 || !ctrl || !num_steps_out || !num_attempts_out || !failed_out)
     return fail(PNODE_EINVAL, "null argument");
   if (!h->initialised) return fail(PNODE_ESTATE, "set_initial has not been called");
-  if (h->dense && !(dense_small_supported(h->dn) && !h->dn.force_generic))
-    return fail(PNODE_EINVAL, "the device-resident controller needs the isotropic model or a dense model with (nu+1)*d <= 32");
+  // dense model beyond the fused one-wavefront kernel: multi-kernel form (controller kernel between the attempts), filter only
+  const bool multi = h->dense && !(dense_small_supported(h->dn) && !h->dn.force_generic);
+  if (multi && h->dn.fixedpoint)
+    return fail(PNODE_EINVAL, "the device-resident controller of the dense model is implemented for strategy_filter");
   if (h->cfg.vf_id == PNODE_VF_USER) return fail(PNODE_EINVAL, "the device-resident controller needs a built-in vector field");
   HIP_TRY(hipSetDevice(h->cfg.device));
   const size_t B = h->cfg.batch;
@@ -708,6 +799,7 @@ int pnode_solve_adaptive_save_at_device(pnode_batch* h, const double* save_at, i
   const double rate = double(h->cfg.nu + 1);
   ControlParams cp{ctrl->safety, ctrl->factor_min, ctrl->factor_max, ctrl->power_integral_unscaled / rate,
                    ctrl->power_proportional_unscaled / rate, nz, ctrl->clip, iters_per_launch > 0 ? iters_per_launch : 4096};
+  const int rounds_per_sync = iters_per_launch > 0 ? (iters_per_launch < 64 ? iters_per_launch : 64) : 8;
   TrajCtl* hCtl = nullptr;
   HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&hCtl), B * sizeof(TrajCtl)));
   TrajCtl* zCtl = nullptr;
@@ -781,15 +873,27 @@ int pnode_solve_adaptive_save_at_device(pnode_batch* h, const double* save_at, i
       c.s_sf = h->s_sf[b]; c.s_if = h->s_if[b]; c.s_pr = h->s_pr[b];
     }
     if (!any) break;
-    if (h->dense)
-      dense_small_launch_advance(h->dn, zCtl, h->dK, cp, h->stream);
-    else
-      iso_launch_advance(h->iso, zCtl, h->dK, cp, h->stream);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    if (e != hipSuccess) {
-      rc = fail(PNODE_EDEVICE, hipGetErrorString(e));
-      break;
+    if (multi) {
+      // until every trajectory handed over has reached its checkpoint (or failed): rounds of attempts without host involvement
+      for (;;) {
+        rc = advance_rounds_device(h, hCtl, cp, rounds_per_sync);
+        if (rc != PNODE_OK) break;
+        bool running = false;
+        for (size_t b = 0; b < B; ++b) running = running || hCtl[b].status == 0;
+        if (!running) break;
+      }
+      if (rc != PNODE_OK) break;
+    } else {
+      if (h->dense)
+        dense_small_launch_advance(h->dn, zCtl, h->dK, cp, h->stream);
+      else
+        iso_launch_advance(h->iso, zCtl, h->dK, cp, h->stream);
+      hipError_t e = hipGetLastError();
+      if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+      if (e != hipSuccess) {
+        rc = fail(PNODE_EDEVICE, hipGetErrorString(e));
+        break;
+      }
     }
     for (size_t b = 0; b < B; ++b) {
       const TrajCtl& c = hCtl[b];
@@ -804,6 +908,42 @@ int pnode_solve_adaptive_save_at_device(pnode_batch* h, const double* save_at, i
   (void)hipHostFree(hCtl);
   if (rc != PNODE_OK) return rc;
   for (size_t b = 0; b < B; ++b) num_attempts_out[b] = attempts[b];
+  return PNODE_OK;
+}
+
+int pnode_advance_device(pnode_batch* h, const double* t_stop, double* dt_inout, double* log_err_prev_inout, const pnode_control* ctrl,
+                         double nz, int32_t rounds, int32_t* status_out, int64_t* attempts_out) {
+  if (!h || !t_stop || !dt_inout || !log_err_prev_inout || !ctrl || !status_out || !attempts_out || rounds < 1)
+    return fail(PNODE_EINVAL, "bad argument");
+  if (!h->initialised) return fail(PNODE_ESTATE, "set_initial has not been called");
+  if (h->dense && h->dn.fixedpoint) return fail(PNODE_EINVAL, "pnode_advance_device: strategy_filter only for the dense model");
+  if (h->cfg.vf_id == PNODE_VF_USER) return fail(PNODE_EINVAL, "the device-resident controller needs a built-in vector field");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  const size_t B = h->cfg.batch;
+  const double rate = double(h->cfg.nu + 1);
+  ControlParams cp{ctrl->safety, ctrl->factor_min, ctrl->factor_max, ctrl->power_integral_unscaled / rate,
+                   ctrl->power_proportional_unscaled / rate, nz, ctrl->clip, 0};
+  std::vector<TrajCtl> c(B);
+  for (size_t b = 0; b < B; ++b) {
+    TrajCtl& x = c[b];
+    x.status = status_out[b] < 0 ? -1 : 0;
+    x.t_sf = h->t_sf[b]; x.t_if = h->t_if[b]; x.dt = dt_inout[b]; x.log_prev = log_err_prev_inout[b]; x.t_stop = t_stop[b];
+    x.steps = h->steps[b]; x.attempts = 0;
+    x.s_sf = h->s_sf[b]; x.s_if = h->s_if[b]; x.s_pr = h->s_pr[b];
+    if (x.status == 0 && !(x.dt > 0.0)) return fail(PNODE_EINVAL, "dt must be positive for the trajectories taking part");
+  }
+  int rc = advance_rounds_device(h, c.data(), cp, rounds);
+  if (rc != PNODE_OK) return rc;
+  for (size_t b = 0; b < B; ++b) {
+    const TrajCtl& x = c[b];
+    status_out[b] = x.status;
+    attempts_out[b] = x.attempts;
+    if (x.status < 0) continue;
+    h->t_sf[b] = x.t_sf; h->t_if[b] = x.t_if; h->steps[b] = x.steps;
+    h->s_sf[b] = int8_t(x.s_sf); h->s_if[b] = int8_t(x.s_if); h->s_pr[b] = int8_t(x.s_pr);
+    h->pending[b] = 0;
+    dt_inout[b] = x.dt; log_err_prev_inout[b] = x.log_prev;
+  }
   return PNODE_OK;
 }
 

@@ -24,7 +24,7 @@ SYMBOLS = (
     "pnode_set_tolerances pnode_attempt_step pnode_user_extrapolate pnode_user_set_vf pnode_commit pnode_interpolate pnode_checkpoint_at_step "
     "pnode_solve_fixed_grid pnode_solve_adaptive_save_at pnode_solve_adaptive_save_at_device pnode_read_mean pnode_read_time pnode_read_output_scale pnode_read_factor "
     "pnode_read_checkpoint_means pnode_smooth_checkpoint_means pnode_last_step_ms pnode_set_phase_timing "
-    "pnode_last_phase_ms pnode_set_generic_path pnode_stream pnode_lq_schedule"
+    "pnode_last_phase_ms pnode_set_generic_path pnode_stream pnode_lq_schedule pnode_advance_device"
 ).split()
 
 
@@ -115,6 +115,7 @@ def load_library():
     lib.pnode_set_generic_path.argtypes = [vp, C.c_int32]
     lib.pnode_last_phase_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.pnode_stream.argtypes = [vp]
+    lib.pnode_advance_device.argtypes = [vp, dp, dp, dp, C.POINTER(PnodeControl), C.c_double, C.c_int32, i32p, i64p]
     lib.pnode_lq_schedule.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_int8), C.c_int32]
     lib.pnode_stream.restype = vp
     for name in SYMBOLS:
@@ -274,6 +275,26 @@ class Batch:
                   steps.ctypes.data_as(C.POINTER(C.c_int64)), attempts.ctypes.data_as(C.POINTER(C.c_int64)),
                   failed.ctypes.data_as(C.POINTER(C.c_uint8))))
         return steps, attempts, failed.astype(bool)
+
+    def advance_device(self, t_stop, dt, log_err_prev, control, numerical_zero, rounds, status=None):
+        """`rounds` attempts with the controller on the device and ONE host synchronisation (pnode_advance_device).
+        dt and log_err_prev are updated in place; returns (status, attempts)."""
+        if not (isinstance(dt, np.ndarray) and dt.dtype == np.float64 and dt.shape == (self.B,) and dt.flags.c_contiguous):
+            raise ValueError(f"dt must be a C-contiguous float64 array of shape ({self.B},) (updated in place)")
+        if not (isinstance(log_err_prev, np.ndarray) and log_err_prev.dtype == np.float64 and log_err_prev.shape == (self.B,)
+                and log_err_prev.flags.c_contiguous):
+            raise ValueError(f"log_err_prev must be a C-contiguous float64 array of shape ({self.B},) (updated in place)")
+        ts = _f64(np.broadcast_to(t_stop, (self.B,)))
+        st = np.zeros(self.B, dtype=np.int32) if status is None else np.ascontiguousarray(status, dtype=np.int32)
+        if st.shape != (self.B,):
+            raise ValueError(f"status must have shape ({self.B},)")
+        att = np.zeros(self.B, dtype=np.int64)
+        ctrl = PnodeControl(control.safety, control.factor_min, control.factor_max, control.power_integral_unscaled,
+                            control.power_proportional_unscaled, int(control.clip), 0)
+        _check(self._lib.pnode_advance_device(self._h, _dp(ts), _dp(dt), _dp(log_err_prev), C.byref(ctrl), float(numerical_zero),
+                                              int(rounds), st.ctypes.data_as(C.POINTER(C.c_int32)),
+                                              att.ctypes.data_as(C.POINTER(C.c_int64))))
+        return st, att
 
     def solve_fixed_grid(self, grid):
         grid = _f64(grid)

@@ -200,6 +200,15 @@ int pnode_set_phase_timing(pnode_batch* h, int32_t enabled);
 int pnode_last_phase_ms(pnode_batch* h, float* ms_out);
 /* Raw stream handle (hipStream_t) for callers that need to order their own work after ours. */
 void* pnode_stream(pnode_batch* h);
+/* Device-resident controller as a building block (/root/reference/src/odecheckpts/ivpsolvers.py:52-53 is the
+ * controller it restates): `rounds` batched attempts are enqueued back to back, each followed by a controller kernel that accepts
+ * or rejects, applies the PI law and prepares the next attempt ON THE DEVICE; the host synchronises once, at the end.
+ * status_out[b]: in < 0 = trajectory does not take part; out 0 = still short of t_stop[b], 1 = STEP_FROM.t + nz >= t_stop[b],
+ * 2 = failed (non-finite). dt_inout / log_err_prev_inout carry the controller state (log of the previous accepted error norm,
+ * 0 initially); attempts_out[b] = attempts made in this call. pnode_solve_adaptive_save_at_device uses it for the dense model
+ * beyond (nu+1) d = 32 (strategy_filter); bench.py uses it for the timed region of the headline. */
+int pnode_advance_device(pnode_batch* h, const double* t_stop, double* dt_inout, double* log_err_prev_inout, const pnode_control* ctrl,
+                         double numerical_zero, int32_t rounds, int32_t* status_out, int64_t* attempts_out);
 /* Host-only (no GPU needed): the table that tells the one-launch LQ kernel of the MFMA fast path which wavefront holds which
  * 16-row strip when (csrc/pnode_device.hpp: LqSchedule), for num_strips = D/16 strips and panels_per_pass panels per pass.
  * Writes the table to out (capacity bytes) and returns its size; PNODE_EINVAL if no table exists for the shape. Lets the

@@ -104,3 +104,36 @@ def test_headline_batch_is_shard_invariant(hip_lib):
         assert np.array_equal(part.num_attempts, whole.num_attempts[lo:hi]), rank
         assert np.array_equal(part.u, whole.u[lo:hi]), rank
         assert np.array_equal(part.output_scale, whole.output_scale[lo:hi]), rank
+
+
+@pytest.mark.parametrize("N", [8, 32])
+def test_device_resident_controller_of_the_dense_model(hip_lib, N):
+    """SURVEY 8(f)-1 for the headline shape: dense EKF1 nu=3 on the Brusselator (N=32: d=64, D=256, MFMA kernels; N=8: generic
+    kernels) with the accept/reject decision and the PI law in a controller kernel between the attempts
+    (`device_controller=True`, pnode_advance_device) against the host controller: identical decisions (accepted steps and
+    attempts per checkpoint), identical step sizes up to the last bits of log/exp, means within 1e-10."""
+    vf = V.brusselator(N)
+    B = 6
+    y0 = np.stack([brusselator_y0(N, 0.7 * b) for b in range(B)])
+    impl.select("dense", ode_shape=(2 * N,))
+    solver = ivpsolvers.solver_dynamic(ivpsolvers.strategy_filter(ivpsolvers.prior_ibm(3), ivpsolvers.correction_ts1()))
+    tol = 10.0 ** -np.linspace(4, 6, B)  # a tolerance sweep: the trajectories need different numbers of attempts
+    asolver = ivpsolve.adaptive(solver, atol=tol, rtol=tol)
+    init = solver.initial_condition(taylor.odejet_padded_scan(vf, [y0], num=3), 1.0)
+    save_at = np.linspace(0.0, 0.4, 5)
+    host = ivpsolve.solve_adaptive_save_at(vf, init, save_at=save_at, dt0=0.01, adaptive_solver=asolver)
+    dev = ivpsolve.solve_adaptive_save_at(vf, init, save_at=save_at, dt0=0.01, adaptive_solver=asolver, device_controller=True)
+    assert np.array_equal(dev.num_steps, host.num_steps)
+    assert np.array_equal(dev.num_attempts, host.num_attempts)
+    assert host.num_steps[:, -1].min() >= 5 and len(set(host.num_steps[:, -1])) > 1
+    assert relmax(dev.u, host.u) < 1e-10
+    # the building block itself: 7 rounds without a host synchronisation advance every trajectory by 7 attempts
+    batch = ivpsolve._make_batch(vf, init, solver, 1)
+    batch.set_initial(init.tcoeffs, np.zeros(B), init.output_scale)
+    batch.set_tolerances(tol, tol)
+    dt, lp = np.full(B, 0.01), np.zeros(B)
+    status, attempts = batch.advance_device(np.full(B, np.inf), dt, lp, asolver.control, asolver.numerical_zero, 7)
+    assert np.all(status == 0) and np.all(attempts == 7)
+    t, steps = batch.read_time()
+    assert np.all(steps >= 1) and np.all(steps <= 7) and np.all(t > 0)
+    batch.close()
