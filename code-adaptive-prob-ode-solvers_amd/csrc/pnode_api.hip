@@ -339,6 +339,7 @@ int pnode_create(const pnode_config* cfg, pnode_batch** out) {
     ALLOC(v.ck_mean, B * Kc * n * d);
     ALLOC(v.ck_fac, B * Kc * n * n);
     ALLOC(v.ck_steps, B * Kc);
+    ALLOC(v.ck_sigma, B * Kc);
     if (v.fixedpoint) {
       ALLOC(v.cG, 3 * B * n * n);
       ALLOC(v.cxi, 3 * B * n * d);
@@ -1111,6 +1112,78 @@ int pnode_smooth_checkpoint_means(pnode_batch* h, const int32_t* num_filled, dou
     e = hipMemcpyAsync(out, dOut, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream);
   }
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  (void)hipFree(dOut);
+  if (e != hipSuccess) return fail(PNODE_EDEVICE, hipGetErrorString(e));
+  return PNODE_OK;
+}
+
+int pnode_offgrid_means(pnode_batch* h, const int32_t* num_filled, const double* init_means, int32_t num_queries, const double* t,
+                        const double* t_lo, const double* t_hi, const int32_t* idx, const uint8_t* at_grid, double* out) {
+  if (!h || !num_filled || !init_means || !t || !t_lo || !t_hi || !idx || !at_grid || !out || num_queries < 1)
+    return fail(PNODE_EINVAL, "bad argument");
+  if (h->dense || !h->iso.fixedpoint)
+    return fail(PNODE_EINVAL, "off-grid marginals need the isotropic model with a stored backward model (smoother / fixedpoint)");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  const size_t B = h->cfg.batch, K = h->cfg.num_checkpoints, Q = size_t(num_queries), nd = size_t(h->n) * h->cfg.d;
+  std::vector<OffgridArg> qa(B * Q);
+  for (size_t b = 0; b < B; ++b) {
+    if (num_filled[b] < 0 || size_t(num_filled[b]) > K) return fail(PNODE_EINVAL, "num_filled out of range");
+    for (size_t q = 0; q < Q; ++q) {
+      const size_t i = b * Q + q;
+      OffgridArg& a = qa[i];
+      a.t = t[i]; a.t_lo = t_lo[i]; a.t_hi = t_hi[i]; a.idx = idx[i]; a.at_grid = at_grid[i] ? 1 : 0;
+      if (a.idx >= num_filled[b]) return fail(PNODE_EINVAL, "query beyond the stored posterior");
+      if (a.idx >= 0 && !a.at_grid && !(a.t > a.t_lo && a.t < a.t_hi)) return fail(PNODE_EINVAL, "query outside its interval");
+    }
+  }
+  double *dSm = nullptr, *dInit = nullptr, *dOut = nullptr;
+  OffgridArg* dQ = nullptr;
+  auto cleanup = [&]() {
+    (void)hipFree(dSm); (void)hipFree(dInit); (void)hipFree(dOut); (void)hipFree(dQ);
+  };
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&dSm), B * (K + 1) * nd * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&dInit), B * nd * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&dOut), B * Q * nd * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&dQ), B * Q * sizeof(OffgridArg));
+  if (e == hipSuccess) e = hipMemsetAsync(dSm, 0, B * (K + 1) * nd * sizeof(double), h->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(dOut, 0, B * Q * nd * sizeof(double), h->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(h->dFilled, num_filled, B * sizeof(int32_t), hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(dInit, init_means, B * nd * sizeof(double), hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(dQ, qa.data(), B * Q * sizeof(OffgridArg), hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess) {
+    iso_launch_smooth(h->iso, h->dFilled, dSm, h->stream);
+    iso_launch_offgrid(h->iso, dQ, int(Q), dInit, dSm, h->dK, dOut, h->stream);
+    e = hipMemcpyAsync(out, dOut, B * Q * nd * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (e == hipSuccess) e = hipGetLastError();
+  cleanup();
+  if (e != hipSuccess) return fail(PNODE_EDEVICE, hipGetErrorString(e));
+  return PNODE_OK;
+}
+
+int pnode_sample_checkpoints(pnode_batch* h, const int32_t* num_filled, int32_t num_samples, const double* eps, double* out) {
+  if (!h || !num_filled || !eps || !out || num_samples < 1) return fail(PNODE_EINVAL, "bad argument");
+  if (h->dense || !h->iso.fixedpoint)
+    return fail(PNODE_EINVAL, "posterior sampling needs the isotropic model with a stored backward model (smoother / fixedpoint)");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  const size_t B = h->cfg.batch, K = h->cfg.num_checkpoints, S = size_t(num_samples), nd = size_t(h->n) * h->cfg.d;
+  for (size_t b = 0; b < B; ++b)
+    if (num_filled[b] < 0 || size_t(num_filled[b]) > K) return fail(PNODE_EINVAL, "num_filled out of range");
+  const size_t cnt = B * S * (K + 1) * nd;
+  double *dEps = nullptr, *dOut = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&dEps), cnt * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&dOut), cnt * sizeof(double));
+  if (e == hipSuccess) e = hipMemsetAsync(dOut, 0, cnt * sizeof(double), h->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(dEps, eps, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(h->dFilled, num_filled, B * sizeof(int32_t), hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess) {
+    iso_launch_sample(h->iso, h->dFilled, int(S), dEps, dOut, h->stream);
+    e = hipMemcpyAsync(out, dOut, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (e == hipSuccess) e = hipGetLastError();
+  (void)hipFree(dEps);
   (void)hipFree(dOut);
   if (e != hipSuccess) return fail(PNODE_EDEVICE, hipGetErrorString(e));
   return PNODE_OK;

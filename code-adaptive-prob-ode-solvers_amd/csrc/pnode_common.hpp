@@ -32,6 +32,13 @@ struct InterpArg {
   int64_t steps;   // num_steps recorded with the checkpoint
 };
 
+// One off-grid query of a stored posterior (iso_offgrid_kernel).
+struct OffgridArg {
+  double t, t_lo, t_hi;  // query time and the stored interval (t_lo, t_hi] that contains it
+  int32_t idx;           // store entry at t_hi (0-based); < 0: skip
+  int32_t at_grid;       // 1: t coincides with t_hi, the smoothed mean there is the answer
+};
+
 // One "predict with backward transition" operation of the dense fixed-point smoother, per trajectory.
 struct FpArg {
   double dt;

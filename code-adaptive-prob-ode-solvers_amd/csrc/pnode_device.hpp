@@ -26,12 +26,16 @@ struct IsoView {
   double* ck_xi;       // [B][K][n][d]
   double* ck_Lam;      // [B][K][n][n]
   int64_t* ck_steps;   // [B][K]
+  double* ck_sigma;    // [B][K]   output scale the stored state was computed with
 };
 
 void iso_launch_step(const IsoView& v, const StepArg* args, const IwpConst* K, hipStream_t s);
 void iso_launch_interp(const IsoView& v, const InterpArg* args, const IwpConst* K, hipStream_t s);
 void iso_launch_advance(const IsoView& v, TrajCtl* ctl, const IwpConst* K, const ControlParams& cp, hipStream_t s);
 void iso_launch_smooth(const IsoView& v, const int32_t* num_filled, double* out, hipStream_t s);
+void iso_launch_offgrid(const IsoView& v, const OffgridArg* qs, int Q, const double* init, const double* smoothed, const IwpConst* K,
+                        double* out, hipStream_t s);
+void iso_launch_sample(const IsoView& v, const int32_t* num_filled, int S, const double* eps, double* out, hipStream_t s);
 
 // Dense model (EKF1 / EKF0 with a full D x D factor), D = n*d.
 struct DenseView {

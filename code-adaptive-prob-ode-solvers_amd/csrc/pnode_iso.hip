@@ -491,7 +491,10 @@ __global__ __launch_bounds__(256) void iso_interp_kernel(IsoView v, const Interp
       store_small<N>(v.cG + (size_t(arg.s1) * sB + b) * N * N, G1, lane);
       store_small<N>(v.cLam + (size_t(arg.s1) * sB + b) * N * N, L1, lane);
     }
-    if (lane == 0) v.ck_steps[ck] = arg.steps;
+    if (lane == 0) {
+      v.ck_steps[ck] = arg.steps;
+      v.ck_sigma[ck] = v.sigma[size_t(arg.s1) * sB + b];
+    }
     return;
   }
 
@@ -526,6 +529,7 @@ __global__ __launch_bounds__(256) void iso_interp_kernel(IsoView v, const Interp
     if (lane == 0) {
       v.sigma[size_t(arg.s0) * sB + b] = sigma;
       v.ck_steps[ck] = arg.steps;
+      v.ck_sigma[ck] = sigma;
     }
     return;
   } else {
@@ -637,6 +641,7 @@ __global__ __launch_bounds__(256) void iso_interp_kernel(IsoView v, const Interp
     if (lane == 0) {
       v.sigma[size_t(arg.s0) * sB + b] = sigma;
       v.ck_steps[ck] = arg.steps;
+      v.ck_sigma[ck] = sigma;
     }
   }
 }
@@ -678,6 +683,132 @@ __global__ __launch_bounds__(256) void iso_smooth_kernel(IsoView v, const int32_
       for (int i = 0; i < N; ++i) {
         m[i] = mn[i];
         ob[size_t(c) * N * d + i * d + j] = mn[i];
+      }
+    }
+  }
+}
+
+// Off-grid marginal means of a stored (smoother / fixed-point) posterior: stats.offgrid_marginals_searchsorted,
+// /root/reference/src/odecheckpts/ivpsolvers.py:118,144. Query q of trajectory b lies in (t_lo, t_hi], the interval that ends at
+// store entry c = idx (c = 0: it starts at the initial state, whose mean is init[b] and whose covariance is zero). Same
+// arithmetic as the checkpoint interpolation above: extrapolate the filtering state at t_lo to t, form the backward transition
+// t_hi -> t from a second extrapolation t -> t_hi (output scale of the state at t_hi), and push the SMOOTHED mean at t_hi
+// (backward pass, `smoothed`) through it. One wavefront per (trajectory, query).
+template <int N>
+__global__ __launch_bounds__(256) void iso_offgrid_kernel(IsoView v, const OffgridArg* __restrict__ qs, int Q,
+                                                          const double* __restrict__ init, const double* __restrict__ smoothed,
+                                                          const IwpConst* __restrict__ Kc, double* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv);
+  if (item >= v.B * Q) return;
+  const int b = item / Q;
+  const OffgridArg a = qs[item];
+  if (a.idx < 0) return;
+  const IwpConst& K = *Kc;
+  const int d = v.d, c = a.idx;
+  const double* ms = smoothed + (size_t(b) * (v.K + 1) + c + 1) * N * d;  // smoothed mean at t_hi
+  double* o = out + size_t(item) * N * d;
+  if (a.at_grid) {
+    for (int j = lane; j < d; j += kWave)
+#pragma unroll
+      for (int i = 0; i < N; ++i) o[i * d + j] = ms[i * d + j];
+    return;
+  }
+  const double* m0 = (c == 0) ? init + size_t(b) * N * d : v.ck_mean + (size_t(b) * v.K + c - 1) * N * d;
+  const double sigma = v.ck_sigma[size_t(b) * v.K + c];
+  double p[N], pinv[N], q[N], qinv[N];
+  preconditioner<N>(a.t - a.t_lo, K, p, pinv);
+  preconditioner<N>(a.t_hi - a.t, K, q, qinv);
+  double R0[N][N], Rt[N][N], Gt[N][N], RLt[N][N], Ru[N][N], G1[N][N], RL1[N][N];
+  if (c == 0) {
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+      for (int j = 0; j < N; ++j) R0[i][j] = 0.0;
+  } else {
+    load_small<N>(v.ck_fac + (size_t(b) * v.K + c - 1) * N * N, R0);
+  }
+  iso_time_update<N, false>(K, R0, p, pinv, sigma, Rt, Gt, RLt);
+  iso_time_update<N, true>(K, Rt, q, qinv, sigma, Ru, G1, RL1);
+  for (int j = lane; j < d; j += kWave) {
+    double mt[N], mt1[N], tmp[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) tmp[i] = pinv[i] * m0[i * d + j];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      double acc = 0.0;
+#pragma unroll
+      for (int kk = i; kk < N; ++kk) acc += K.a[i][kk] * tmp[kk];
+      mt[i] = p[i] * acc;  // filtering mean at t
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) tmp[i] = qinv[i] * mt[i];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      double acc = 0.0;
+#pragma unroll
+      for (int kk = i; kk < N; ++kk) acc += K.a[i][kk] * tmp[kk];
+      mt1[i] = q[i] * acc;  // prediction of t_hi from t
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      double acc = mt[i];
+#pragma unroll
+      for (int kk = 0; kk < N; ++kk) acc += G1[i][kk] * (ms[kk * d + j] - mt1[kk]);
+      o[i * d + j] = acc;
+    }
+  }
+}
+
+// Joint samples of the stored posterior, backwards from the terminal marginal (stats.markov_sample(..., reverse=True),
+// /root/reference/experiments/5_vs_interpolation/measure.py:69-75): x_T = m_T + R_T^T e_T, x_c = G_c x_{c+1} + xi_c + Lam_c^T e_c.
+// eps / out: [B][S][K+1][n][d] (entry 0 = initial time, entry c+1 = store entry c); the host supplies the standard-normal base
+// samples, so a run is reproducible against the oracle. One wavefront per (trajectory, sample).
+template <int N>
+__global__ __launch_bounds__(256) void iso_sample_kernel(IsoView v, const int32_t* __restrict__ num_filled, int S,
+                                                         const double* __restrict__ eps, double* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv);
+  if (item >= v.B * S) return;
+  const int b = item / S;
+  const int nf = num_filled[b];
+  if (nf <= 0) return;
+  const int d = v.d;
+  const double* e = eps + size_t(item) * (v.K + 1) * N * d;
+  double* o = out + size_t(item) * (v.K + 1) * N * d;
+  double RT[N][N];
+  load_small<N>(v.ck_fac + (size_t(b) * v.K + nf - 1) * N * N, RT);
+  for (int j = lane; j < d; j += kWave) {
+    double x[N];
+    const double* mT = v.ck_mean + (size_t(b) * v.K + nf - 1) * N * d;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      double acc = mT[i * d + j];
+#pragma unroll
+      for (int kk = 0; kk <= i; ++kk) acc += RT[kk][i] * e[(size_t(nf) * N + kk) * d + j];  // R upper: (R^T e)_i = sum_{k <= i} R[k][i] e_k
+      x[i] = acc;
+      o[(size_t(nf) * N + i) * d + j] = acc;
+    }
+    for (int c = nf - 1; c >= 0; --c) {
+      const double* Gc = v.ck_G + (size_t(b) * v.K + c) * N * N;
+      const double* Lc = v.ck_Lam + (size_t(b) * v.K + c) * N * N;
+      const double* xc = v.ck_xi + (size_t(b) * v.K + c) * N * d;
+      double xn[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        double acc = xc[i * d + j];
+#pragma unroll
+        for (int kk = 0; kk < N; ++kk) acc += Gc[i * N + kk] * x[kk];
+#pragma unroll
+        for (int kk = 0; kk <= i; ++kk) acc += Lc[kk * N + i] * e[(size_t(c) * N + kk) * d + j];
+        xn[i] = acc;
+      }
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        x[i] = xn[i];
+        o[(size_t(c) * N + i) * d + j] = xn[i];
       }
     }
   }
@@ -756,6 +887,19 @@ static void launch_advance_n(const IsoView& v, TrajCtl* ctl, const IwpConst* K, 
 }
 void iso_launch_advance(const IsoView& v, TrajCtl* ctl, const IwpConst* K, const ControlParams& cp, hipStream_t s) {
 #define CALL(NN) launch_advance_n<NN>(v, ctl, K, cp, s)
+  PNODE_DISPATCH_N(v.n, CALL)
+#undef CALL
+}
+void iso_launch_offgrid(const IsoView& v, const OffgridArg* qs, int Q, const double* init, const double* smoothed, const IwpConst* K,
+                        double* out, hipStream_t s) {
+  const int blocks = (v.B * Q + 3) / 4;
+#define CALL(NN) hipLaunchKernelGGL((iso_offgrid_kernel<NN>), dim3(blocks), dim3(256), 0, s, v, qs, Q, init, smoothed, K, out)
+  PNODE_DISPATCH_N(v.n, CALL)
+#undef CALL
+}
+void iso_launch_sample(const IsoView& v, const int32_t* num_filled, int S, const double* eps, double* out, hipStream_t s) {
+  const int blocks = (v.B * S + 3) / 4;
+#define CALL(NN) hipLaunchKernelGGL((iso_sample_kernel<NN>), dim3(blocks), dim3(256), 0, s, v, num_filled, S, eps, out)
   PNODE_DISPATCH_N(v.n, CALL)
 #undef CALL
 }

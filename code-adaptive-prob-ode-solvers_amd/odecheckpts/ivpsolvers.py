@@ -14,7 +14,6 @@ from __future__ import annotations
 import warnings
 
 import numpy as np
-import scipy.integrate
 from probdiffeq_hip import ivpsolve, ivpsolvers, stats, taylor
 from probdiffeq_hip.impl import impl
 
@@ -62,28 +61,39 @@ def solve(method: str, vf, u0_like, /, save_at, *, dt0, atol, rtol, ode_order=1,
 
 
 def solve_via_interpolate(method: str, vf, u0_like, /, save_at, *, dt0, atol, rtol):
-    raise NotImplementedError(
-        "solve_via_interpolate is the store-every-step smoother baseline the reference argues against "
-        "(ivpsolvers.py:94-148); it is outside the hot-path scope (SURVEY.md section 2, row 2)."
-    )
+    """The reference's "textbook" baseline (ivpsolvers.py:94-148): isotropic IWP(nu) + EKF0 with strategy_smoother and dynamic
+    calibration, adaptive steps over [save_at[0] - 1e-6, save_at[-1] + 1e-6] with EVERY accepted step stored, then the posterior
+    evaluated at `save_at` between the steps. Same signature and return structure as `solve`; one IVP per call (the number of
+    stored steps differs between trajectories)."""
+    small_value = 1e-6
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        like = np.asarray(u0_like[0] if isinstance(u0_like, tuple) else u0_like)
+        impl.select("isotropic", ode_shape=like.shape[-1:] if like.ndim else ())
+    if method[:3] != "ts0" or not method[-1].isdigit():
+        raise ValueError(f"unknown method {method!r}: expected 'ts0-<num_derivatives>'")
+    num_derivatives = int(method[-1])
+    strategy = ivpsolvers.strategy_smoother(ivpsolvers.prior_ibm(num_derivatives=num_derivatives), ivpsolvers.correction_ts0())
+    solver = ivpsolvers.solver_dynamic(strategy)
+    asolver = ivpsolve.adaptive(solver, atol=atol, rtol=rtol, control=ivpsolve.control_proportional_integral())
+    save_at = np.asarray(save_at, dtype=np.float64)
+
+    def solve_(u0: tuple, p, output_scale=1.0):
+        if not isinstance(u0, tuple):
+            raise ValueError("Tuple expected.")
+        vf_bound = vf.bind(p)
+        tcoeffs = taylor.odejet_padded_scan(vf_bound, u0, num=num_derivatives)
+        init = solver.initial_condition(tcoeffs, output_scale=output_scale)
+        if init.batched:
+            raise ValueError("solve_via_interpolate stores every accepted step: one initial value problem per call")
+        # small perturbation so that all save_at values are in the interior of the domain (ivpsolvers.py:135-139)
+        sol = ivpsolve.solve_adaptive_save_every_step(vf_bound, init, t0=save_at[0] - small_value, t1=save_at[-1] + small_value,
+                                                      dt0=dt0, adaptive_solver=asolver)
+        dense, _ = stats.offgrid_marginals_searchsorted(ts=save_at, solution=sol, solver=solver)
+        return dense, {"solution": sol, "u0_solve": sol.u}
+
+    return solve_
 
 
 def solve_diffrax(method: str, vf, _u0_like, /, save_at, *, dt0, atol, rtol, ode_order=1):
     raise NotImplementedError("diffrax Runge-Kutta competitors are outside the hot-path scope (SURVEY.md section 2, row 3)")
-
-
-def asolve_scipy(method: str, vf, /, time_span, *, atol, rtol):
-    """Plot-quality truth with scipy (ivpsolvers.py:196-210); host-side, used by tests as an independent check."""
-
-    def solve_(u0: tuple, p):
-        if not isinstance(u0, tuple):
-            raise ValueError("Tuple expected.")
-
-        def vf_scipy(t, y):
-            return vf(y, t=t, p=p)
-
-        (y0,) = u0
-        solution = scipy.integrate.solve_ivp(vf_scipy, y0=y0, t_span=time_span, atol=atol, rtol=rtol, method=method)
-        return solution.t, solution.y.T
-
-    return solve_

@@ -115,6 +115,8 @@ def load_library():
     lib.pnode_set_generic_path.argtypes = [vp, C.c_int32]
     lib.pnode_last_phase_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.pnode_stream.argtypes = [vp]
+    lib.pnode_offgrid_means.argtypes = [vp, i32p, dp, C.c_int32, dp, dp, dp, i32p, u8p, dp]
+    lib.pnode_sample_checkpoints.argtypes = [vp, i32p, C.c_int32, dp, dp]
     lib.pnode_advance_device.argtypes = [vp, dp, dp, dp, C.POINTER(PnodeControl), C.c_double, C.c_int32, i32p, i64p]
     lib.pnode_lq_schedule.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_int8), C.c_int32]
     lib.pnode_stream.restype = vp
@@ -338,6 +340,34 @@ class Batch:
         nf = self._slots(num_filled)
         out = np.zeros((self.B, self.K + 1, self.n, self.d))
         _check(self._lib.pnode_smooth_checkpoint_means(self._h, nf.ctypes.data_as(C.POINTER(C.c_int32)), _dp(out)))
+        return out
+
+    def offgrid_means(self, num_filled, init_means, t, t_lo, t_hi, idx, at_grid):
+        """Off-grid marginal means (B, Q, n, d) of the stored posterior (pnode_offgrid_means)."""
+        nf = self._slots(num_filled)
+        t = _f64(t)
+        if t.ndim != 2 or t.shape[0] != self.B:
+            raise ValueError(f"t must have shape ({self.B}, Q)")
+        Q = t.shape[1]
+        t_lo, t_hi = _f64(t_lo, (self.B, Q)), _f64(t_hi, (self.B, Q))
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        ag = np.ascontiguousarray(at_grid, dtype=np.uint8)
+        if idx.shape != (self.B, Q) or ag.shape != (self.B, Q):
+            raise ValueError(f"idx and at_grid must have shape ({self.B}, {Q})")
+        init = _f64(init_means, (self.B, self.n, self.d))
+        out = np.zeros((self.B, Q, self.n, self.d))
+        _check(self._lib.pnode_offgrid_means(self._h, nf.ctypes.data_as(C.POINTER(C.c_int32)), _dp(init), Q, _dp(t), _dp(t_lo), _dp(t_hi),
+                                             idx.ctypes.data_as(C.POINTER(C.c_int32)), ag.ctypes.data_as(C.POINTER(C.c_uint8)), _dp(out)))
+        return out
+
+    def sample_checkpoints(self, num_filled, eps):
+        """Joint posterior samples (B, S, K+1, n, d) from base samples eps of the same shape (pnode_sample_checkpoints)."""
+        nf = self._slots(num_filled)
+        eps = _f64(eps)
+        if eps.ndim != 5 or eps.shape[0] != self.B or eps.shape[2:] != (self.K + 1, self.n, self.d):
+            raise ValueError(f"eps must have shape ({self.B}, S, {self.K + 1}, {self.n}, {self.d})")
+        out = np.zeros_like(eps)
+        _check(self._lib.pnode_sample_checkpoints(self._h, nf.ctypes.data_as(C.POINTER(C.c_int32)), eps.shape[1], _dp(eps), _dp(out)))
         return out
 
     def set_generic_path(self, enabled=True):

@@ -69,11 +69,19 @@ def adaptive(solver: Solver, atol=1e-4, rtol=1e-2, control=None, norm_ord=None, 
 
 @dataclasses.dataclass
 class Posterior:
-    """Means of the posterior at the returned time points (+ the live device batch for more reads)."""
+    """Means of the posterior at the returned time points (+ the live device batch for more reads).
+
+    For the strategies that store a backward model (fixedpoint: one transition per save_at interval; smoother: one per
+    accepted step) `grid`, `num_filled` and `init_means` describe the store on the device, which
+    `stats.offgrid_marginals_searchsorted` and `stats.markov_sample` evaluate there."""
 
     means: np.ndarray  # (B, T, n, d)
-    kind: str  # "filter" | "fixedpoint"
+    kind: str  # "filter" | "fixedpoint" | "smoother"
     batch: object = None
+    grid: np.ndarray = None  # (B, K+1) times of the stored entries, grid[:, 0] = t0 (NaN beyond num_filled)
+    num_filled: np.ndarray = None  # (B,) stored entries per trajectory
+    init_means: np.ndarray = None  # (B, n, d) mean of the initial condition
+    index: int = None  # set when this object describes ONE trajectory of a batched solve
 
 
 @dataclasses.dataclass
@@ -107,13 +115,18 @@ def _make_batch(vf, init: InitialCondition, solver: Solver, num_checkpoints, dev
                          f"d={d}, order={st.correction.ode_order}")
     if st.ode_shape not in ((), (d,)):
         raise ValueError(f"impl.select ode_shape {st.ode_shape} does not match the initial condition (d={d})")
-    if st.kind == "smoother":
-        raise NotImplementedError("strategy_smoother (O(#steps) memory) is outside the hot-path scope; "
-                                  "use strategy_fixedpoint with solve_adaptive_save_at")
+    kind = st.kind
+    if kind == "smoother":
+        # one stored backward transition per accepted step: the fixed-point machinery with a checkpoint at every step
+        # (solve_adaptive_save_every_step drives it); the store holds num_checkpoints steps
+        if st.model != "isotropic":
+            raise NotImplementedError("strategy_smoother is implemented for the isotropic model (the reference's use, "
+                                      "src/odecheckpts/ivpsolvers.py:102-112); use strategy_fixedpoint with the dense model")
+        kind = "fixedpoint"
     prm = vf.param_array()
     batch = _backend.Batch(
         batch=B, d=d, nu=st.prior.num_derivatives, ode_order=st.correction.ode_order, model=st.model,
-        correction=st.correction.kind, strategy=st.kind, calibration=solver.calibration, vf_id=vf.vf_id,
+        correction=st.correction.kind, strategy=kind, calibration=solver.calibration, vf_id=vf.vf_id,
         vf_params=prm, num_checkpoints=num_checkpoints, device=device,
     )
     return batch
@@ -229,7 +242,8 @@ def solve_adaptive_save_at(vector_field, initial_condition: InitialCondition, sa
     """
     solver = adaptive_solver.solver
     if not solver.strategy.is_suitable_for_save_at:
-        warnings.warn("strategy is not suitable for save_at", stacklevel=2)
+        raise ValueError("strategy_smoother stores every step: use solve_adaptive_save_every_step (+ "
+                         "stats.offgrid_marginals_searchsorted), or strategy_fixedpoint with solve_adaptive_save_at")
     init = initial_condition
     B, n, d = init.tcoeffs.shape
     sa = np.asarray(save_at, dtype=np.float64)
@@ -259,8 +273,14 @@ def solve_adaptive_save_at(vector_field, initial_condition: InitialCondition, sa
     if loop.failed.any():
         for b in np.nonzero(loop.failed)[0]:
             means[b, cursor[b]:] = np.nan
-    return _finish(means, init, solver.strategy.kind, batch, sa if sa.ndim == 1 else sa_b, num_steps, loop,
-                   not init.batched)
+    sol = _finish(means, init, solver.strategy.kind, batch, sa if sa.ndim == 1 else sa_b, num_steps, loop,
+                  not init.batched)
+    if solver.strategy.kind == "fixedpoint":
+        sol.posterior.grid = sa_b
+        sol.posterior.num_filled = np.minimum(cursor - 1, K).astype(np.int32)
+        sol.posterior.init_means = init.tcoeffs
+        sol.posterior.index = None if init.batched else 0
+    return sol
 
 
 def solve_adaptive_terminal_values(vector_field, initial_condition: InitialCondition, t0, t1,
@@ -277,15 +297,68 @@ def solve_adaptive_terminal_values(vector_field, initial_condition: InitialCondi
     return Solution(sa[:, 1], sol.u[:, -1], post, sol.output_scale, sol.num_steps[:, -1], sol.num_attempts)
 
 
+def _save_every_step_smoother(vector_field, init, t0b, t1b, adaptive_solver, dt0, device, max_steps):
+    """strategy_smoother: every accepted step is stored on the device with its own backward transition (memory O(#steps),
+    the 'textbook' baseline of experiments/4_brusselator/run.py:102-117 and src/odecheckpts/ivpsolvers.py:112,133-142);
+    the solution is the backward pass over all of them."""
+    solver = adaptive_solver.solver
+    B = init.tcoeffs.shape[0]
+    batch = _make_batch(vector_field, init, solver, max_steps, device)
+    batch.set_initial(init.tcoeffs, t0b, init.output_scale)
+    batch.set_tolerances(adaptive_solver.atol, adaptive_solver.rtol)
+    loop = _AdaptiveLoop(batch, adaptive_solver, t0b, dt0, vf=vector_field)
+    grid = np.full((B, max_steps + 1), np.nan)
+    grid[:, 0] = t0b
+    count = np.zeros(B, dtype=np.int64)
+    done = np.zeros(B, dtype=bool)
+    rows = np.arange(B)
+    while True:
+        active = ~done & ~loop.failed
+        if not active.any():
+            break
+        if np.any(count[active] >= max_steps):
+            raise RuntimeError(f"strategy_smoother stores every accepted step and max_steps={max_steps} is used up; "
+                               "raise max_steps or use strategy_fixedpoint with solve_adaptive_save_at (fixed memory)")
+        acc = loop.attempt(active, t1=t1b)
+        over = acc & (loop.t > t1b)  # (same end-point rule as the filter's driver below: exact comparisons)
+        corner = acc & ~over
+        if corner.any():
+            batch.checkpoint_at_step(np.where(corner, count, -1))
+            grid[rows[corner], count[corner] + 1] = loop.t[corner]
+        if over.any():  # the last step oversteps t1: the solution at t1 is interpolated, the overshooting state dropped
+            batch.interpolate(np.where(over, t1b, 0.0), np.where(over, count, -1))
+            grid[rows[over], count[over] + 1] = t1b[over]
+        count = count + acc
+        done |= over | (corner & (loop.t >= t1b))
+    means = batch.smooth_checkpoint_means(count.astype(np.int32))
+    scale = batch.read_output_scale(0)
+    sols = []
+    for b in range(B):
+        T = int(count[b]) + 1
+        m = means[b, :T].copy()
+        if loop.failed[b]:
+            m[:] = np.nan
+        post = Posterior(m[None], "smoother", batch, grid, count.astype(np.int32), init.tcoeffs, b)
+        sols.append(Solution(grid[b, :T].copy(), m[:, 0, :], post, scale[b], np.arange(T).clip(max=int(loop.steps[b])),
+                             int(loop.attempts[b])))
+    return sols if init.batched else sols[0]
+
+
 def solve_adaptive_save_every_step(vector_field, initial_condition: InitialCondition, t0, t1,
-                                   adaptive_solver: AdaptiveSolver, dt0, *, device=None):
+                                   adaptive_solver: AdaptiveSolver, dt0, *, device=None, max_steps=4096):
     """Adaptive solve that returns every accepted step (vdp.py:77-79). Ragged over the batch: returns a
     Solution for an unbatched initial condition and a list of Solutions otherwise. Meant for small
-    problems: each accepted batched step copies the means back to the host."""
+    problems: each accepted batched step copies the means back to the host (strategy_filter) or stores the step with its
+    backward transition on the device (strategy_smoother, at most `max_steps` accepted steps per trajectory)."""
     solver = adaptive_solver.solver
+    if solver.strategy.kind == "smoother":
+        B0 = initial_condition.tcoeffs.shape[0]
+        return _save_every_step_smoother(vector_field, initial_condition, np.array(np.broadcast_to(t0, (B0,)), dtype=np.float64),
+                                         np.array(np.broadcast_to(t1, (B0,)), dtype=np.float64), adaptive_solver, dt0, device,
+                                         int(max_steps))
     if solver.strategy.kind != "filter":
-        raise NotImplementedError("solve_adaptive_save_every_step is implemented for strategy_filter "
-                                  "(the reference's use, vdp.py:65); use solve_adaptive_save_at with fixedpoint")
+        raise NotImplementedError("solve_adaptive_save_every_step is implemented for strategy_filter (vdp.py:65) and "
+                                  "strategy_smoother (ivpsolvers.py:112); use solve_adaptive_save_at with fixedpoint")
     init = initial_condition
     B, n, d = init.tcoeffs.shape
     t0b = np.array(np.broadcast_to(t0, (B,)), dtype=np.float64)
@@ -328,6 +401,9 @@ def solve_adaptive_save_every_step(vector_field, initial_condition: InitialCondi
 def solve_fixed_grid(vector_field, initial_condition: InitialCondition, grid, solver: Solver, *, device=None) -> Solution:
     """Pure predict/correct loop on a prescribed grid, no controller (vdp.py:88-103). All launches are
     enqueued on the device stream without host synchronisation. grid: (G,) shared or (B, G)."""
+    if solver.strategy.kind == "smoother":
+        raise NotImplementedError("solve_fixed_grid is implemented for strategy_filter / strategy_fixedpoint; a smoother solve "
+                                  "goes through solve_adaptive_save_every_step")
     init = initial_condition
     B, n, d = init.tcoeffs.shape
     grid = np.asarray(grid, dtype=np.float64)

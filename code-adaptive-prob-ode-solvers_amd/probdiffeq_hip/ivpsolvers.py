@@ -37,6 +37,10 @@ class Strategy:
     def is_suitable_for_save_at(self):
         return self.kind in ("filter", "fixedpoint")
 
+    @property
+    def is_suitable_for_save_every_step(self):
+        return self.kind in ("filter", "smoother")
+
 
 @dataclasses.dataclass(frozen=True)
 class InitialCondition:
@@ -102,9 +106,9 @@ def strategy_fixedpoint(prior: Prior, correction: Correction) -> Strategy:
 
 
 def strategy_smoother(prior: Prior, correction: Correction) -> Strategy:
-    """Stores one backward transition per step (O(#steps) memory): the baseline the reference argues
-    against (ivpsolvers.py:112, run.py:103). Out of the hot-path scope: constructing it works, solving
-    with it raises NotImplementedError in ivpsolve."""
+    """Stores one backward transition per accepted step (O(#steps) memory): the 'textbook' baseline the reference
+    compares against (ivpsolvers.py:112, run.py:103). Isotropic model, through ivpsolve.solve_adaptive_save_every_step;
+    stats.offgrid_marginals_searchsorted evaluates the posterior between the steps."""
     return _strategy("smoother", prior, correction)
 
 

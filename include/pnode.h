@@ -183,6 +183,19 @@ int pnode_read_checkpoint_means(pnode_batch* h, double* out);
  * last stored checkpoint. out: [B][K][nu+1][d] smoothed means. */
 int pnode_smooth_checkpoint_means(pnode_batch* h, const int32_t* num_filled, double* out);
 
+/* Off-grid marginal means of the stored posterior (isotropic model, smoother / fixedpoint): stats.offgrid_marginals_searchsorted
+ * as called at /root/reference/src/odecheckpts/ivpsolvers.py:118,144. The backward pass runs first (as in
+ * pnode_smooth_checkpoint_means); query (b, q) at time t[b][q] lies in the stored interval (t_lo, t_hi] that ENDS at store entry
+ * idx[b][q] (0-based; entry 0 ends the interval that starts at the initial state, whose means are init_means[B][nu+1][d]);
+ * at_grid = 1: t equals t_hi, the smoothed mean there is returned; idx < 0: skipped (zeros). out: [B][Q][nu+1][d]. */
+int pnode_offgrid_means(pnode_batch* h, const int32_t* num_filled, const double* init_means, int32_t num_queries, const double* t,
+                        const double* t_lo, const double* t_hi, const int32_t* idx, const uint8_t* at_grid, double* out);
+/* Joint samples of the stored posterior, backwards from the terminal marginal (isotropic model, smoother / fixedpoint):
+ * stats.markov_sample(key, markov_seq, shape=(S,), reverse=True), /root/reference/experiments/5_vs_interpolation/measure.py:69-75.
+ * eps: standard-normal base samples [B][S][K+1][nu+1][d] from the caller (entry 0 = initial time, entry c+1 = store entry c);
+ * out: the samples, same layout. */
+int pnode_sample_checkpoints(pnode_batch* h, const int32_t* num_filled, int32_t num_samples, const double* eps, double* out);
+
 /* Timing of the device work of the most recent attempt_step (HIP events on the handle's stream),
  * in milliseconds; used by bench.py for the roofline line. Needs pnode_set_phase_timing(h, 1). */
 int pnode_last_step_ms(pnode_batch* h, float* ms_out);

@@ -543,6 +543,58 @@ def markov_marginals_reverse(cfg, sol: Solution):
     return np.stack(out[::-1])
 
 
+def markov_marginal_chols_reverse(cfg, sol: Solution):
+    """Cholesky factors (left factors, cov = C C^T) of the smoothing marginals at every stored point, ordered in time."""
+    states = sol.states
+    chol = states[-1].chol
+    out = [chol]
+    for s in reversed(states[1:]):
+        c = s.cond
+        chol = qr_r(np.concatenate([(c.G @ chol).T, c.Lam.T], axis=0)).T
+        out.append(chol)
+    return out[::-1]
+
+
+def smoother_solution(cfg_fixedpoint, acfg, prob, init: State, t1, dt0) -> Solution:
+    """strategy_smoother + solve_adaptive_save_every_step (/root/reference/src/odecheckpts/ivpsolvers.py:112,133-142;
+    experiments/4_brusselator/run.py:102-117) restated through the fixed-point smoother this oracle pins on the goldens:
+    the accepted grid does not depend on the strategy (the error estimate is the filter's), and a fixed-point solve whose
+    save_at IS that grid stores exactly one backward transition per accepted step, which is what the smoother stores."""
+    cfg_filter = dataclasses.replace(cfg_fixedpoint, strategy="filter")
+    grid = solve_adaptive_save_every_step(cfg_filter, acfg, prob, init, t1, dt0).t
+    return solve_adaptive_save_at(cfg_fixedpoint, acfg, prob, init, grid, dt0)
+
+
+def offgrid_marginal_means(cfg_fixedpoint, acfg, prob, init: State, grid, ts, dt0):
+    """stats.offgrid_marginals_searchsorted (ivpsolvers.py:118,144): smoothing means at `ts` given the accepted grid, as a
+    fixed-point solve over the union of the grid and the query points (an interpolated checkpoint IS the off-grid marginal)."""
+    ts = np.asarray(ts, dtype=np.float64)
+    both = np.union1d(np.asarray(grid, dtype=np.float64), ts)
+    sol = solve_adaptive_save_at(cfg_fixedpoint, acfg, prob, init, both, dt0)
+    means = markov_marginals_reverse(cfg_fixedpoint, sol)
+    return means[np.searchsorted(both, ts)]
+
+
+def markov_sample_reverse(cfg, sol: Solution, eps):
+    """stats.markov_sample(key, markov_seq, reverse=True) (experiments/5_vs_interpolation/measure.py:69-75) for ONE joint
+    sample with base samples eps[(len(t), n, d)] (isotropic model): x_T = m_T + C_T e_T, x_i = G x_{i+1} + xi + Lam e_i, with
+    the triangular factors normalised to a non-negative diagonal (the sign convention of a factor is not part of the model)."""
+    assert cfg.model == "isotropic"
+
+    def pos(f):
+        sg = np.where(np.diag(f) < 0, -1.0, 1.0)
+        return f * sg[None, :]
+
+    states = sol.states
+    x = states[-1].mean + pos(states[-1].chol) @ eps[-1]
+    out = [x]
+    for i in range(len(states) - 1, 0, -1):
+        c = states[i].cond
+        x = c.G @ x + c.xi + pos(c.Lam) @ eps[i - 1]
+        out.append(x)
+    return np.stack(out[::-1])
+
+
 # --------------------------------------------------------------------------------------------
 # Taylor-mode initialisation (taylor.odejet_padded_scan / odejet_unroll) without autodiff:
 # truncated power-series arithmetic on the normalised coefficients c_k = u^(k)(t0) / k!.

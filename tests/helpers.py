@@ -37,3 +37,14 @@ def tcoeffs(vf, u0s, nu):
 
 def oracle_state_from(cfg, means, chol, t, sigma, cond=None):
     return po.State(float(t), np.array(means), np.array(chol), float(sigma), 0, cond)
+
+
+def scipy_truth(vf, y0, t_eval, method="DOP853"):
+    """Independent Runge-Kutta solution of a first-order problem at `t_eval` (tolerances 1e-12): the stand-in for the
+    diffrax solvers the reference's test compares with (tests/test_ivpsolvers.py:11-24)."""
+    import scipy.integrate
+
+    t_eval = np.asarray(t_eval, dtype=np.float64)
+    sol = scipy.integrate.solve_ivp(lambda t, y: np.asarray(vf(y, t=t)), (t_eval[0], t_eval[-1]), np.asarray(y0, dtype=np.float64),
+                                    method=method, rtol=1e-12, atol=1e-12, t_eval=t_eval)
+    return sol.y.T

@@ -7,7 +7,7 @@ posterior means (BASELINE north star), with accept/reject sequences required to 
 import numpy as np
 import pn_oracle as po
 import pytest
-from helpers import brusselator_y0, oracle_problem, tcoeffs
+from helpers import brusselator_y0, oracle_problem, scipy_truth, tcoeffs
 from probdiffeq_hip import _backend, ivpsolve, ivpsolvers, stats
 from probdiffeq_hip import vector_fields as V
 from probdiffeq_hip.impl import impl
@@ -457,8 +457,7 @@ def test_odecheckpts_solve_like_the_reference_test(hip_lib, method):
     solve1 = l3.solve(method, vf, u0[0], save_at, dt0=dt0, atol=atol, rtol=rtol)
     solution1, aux1 = solve1(u0, args)
     assert "u0_solve" in aux1 and "solution" in aux1
-    ts, ys = l3.asolve_scipy("LSODA", vf, time_span, atol=1e-12, rtol=1e-12)(u0, args)
-    truth = np.stack([np.interp(save_at, ts, ys[:, j]) for j in range(ys.shape[1])], axis=1)
+    truth = scipy_truth(vf.bind(args), u0[0], save_at)
     assert solution1.shape == truth.shape == (5, 1)
     assert np.allclose(solution1, truth, atol=np.sqrt(atol), rtol=np.sqrt(rtol))
     # batched call: three initial values at once, each equal to its own single solve

@@ -1,0 +1,129 @@
+"""SURVEY 8(f) rows 2-3 on the GPU: strategy_smoother through solve_adaptive_save_every_step, off-grid marginals,
+`odecheckpts.solve_via_interpolate` (the second half of the reference's only test, tests/test_ivpsolvers.py:19-24) and joint
+posterior samples (`stats.markov_sample`, experiments/5_vs_interpolation/measure.py:69-75), against the oracle and scipy."""
+
+import numpy as np
+import pn_oracle as po
+import pytest
+from helpers import brusselator_y0, oracle_problem, scipy_truth, tcoeffs
+from probdiffeq_hip import ivpsolve, ivpsolvers, stats
+from probdiffeq_hip import vector_fields as V
+from probdiffeq_hip.impl import impl
+
+pytestmark = pytest.mark.gpu
+
+
+def relmax(a, b):
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+def _brusselator_case(nu=3, tol=1e-5):
+    N = 4
+    vf = V.brusselator(N)
+    impl.select("isotropic", ode_shape=(2 * N,))
+    tcs = tcoeffs(vf, [brusselator_y0(N)], nu)
+    cfg = po.SolverConfig(nu=nu, model="isotropic", correction="ts0", strategy="fixedpoint", calibration="dynamic")
+    return vf, tcs, cfg, po.AdaptiveConfig(tol, tol), tol
+
+
+@pytest.mark.parametrize("nu", [2, 4])
+def test_smoother_every_step_and_offgrid_marginals_vs_oracle(hip_lib, nu):
+    """Every accepted step stored with its backward transition: accepted grid, smoothed means at all steps and off-grid
+    marginal means against the oracle; and the paper's statement itself on the device: the fixed-memory fixed-point solve
+    returns the same marginals at save_at as the store-everything smoother evaluated there."""
+    vf, tcs, cfg, acfg, tol = _brusselator_case(nu)
+    prior, corr = ivpsolvers.prior_ibm(nu), ivpsolvers.correction_ts0()
+    smoother = ivpsolvers.solver_dynamic(ivpsolvers.strategy_smoother(prior, corr))
+    init = smoother.initial_condition(tcs, 1.0)
+    sol = ivpsolve.solve_adaptive_save_every_step(vf, init, t0=0.0, t1=1.0, dt0=0.01,
+                                                  adaptive_solver=ivpsolve.adaptive(smoother, atol=tol, rtol=tol))
+    prob, ostate = oracle_problem(vf), po.initial_state(cfg, tcs, 0.0)
+    osol = po.smoother_solution(cfg, acfg, prob, ostate, 1.0, 0.01)
+    # (the step sizes inherit the ~1e-8 relative rounding noise of the error norm through the controller)
+    assert len(sol.t) == len(osol.t) and np.max(np.abs(sol.t - osol.t)) < 1e-8 and sol.t[-1] == 1.0
+    sm = po.markov_marginals_reverse(cfg, osol)
+    assert relmax(sol.u, sm[:, 0]) < 1e-8
+    assert relmax(sol.posterior.means[0, :, 1], sm[:, 1]) < 1e-6
+    # off-grid: interior points, a stored point, the end points
+    ts = np.array([0.0, 0.013, 0.5, float(sol.t[7]), 0.731, 0.9999, 1.0])
+    dense, margs = stats.offgrid_marginals_searchsorted(ts=ts, solution=sol, solver=smoother)
+    ref = po.offgrid_marginal_means(cfg, acfg, prob, ostate, osol.t, ts, 0.01)
+    assert dense.shape == (len(ts), vf.d) and margs.mean.shape == (len(ts), nu + 1, vf.d)
+    assert relmax(dense, ref[:, 0]) < 1e-8
+    assert relmax(margs.mean[:, 1], ref[:, 1]) < 1e-6
+    assert np.array_equal(dense[3], sol.u[7])
+    # fixed memory == store everything, at save_at (both solves take the same steps: nothing clips the step size)
+    fixedpoint = ivpsolvers.solver_dynamic(ivpsolvers.strategy_fixedpoint(prior, corr))
+    save_at = np.linspace(0.0, 1.0, 6)
+    fp = ivpsolve.solve_adaptive_save_at(vf, fixedpoint.initial_condition(tcs, 1.0), save_at=save_at, dt0=0.01,
+                                         adaptive_solver=ivpsolve.adaptive(fixedpoint, atol=tol, rtol=tol))
+    dense2, _ = stats.offgrid_marginals_searchsorted(ts=save_at, solution=sol, solver=smoother)
+    assert relmax(dense2, fp.u) < 1e-8
+    assert int(fp.num_steps[-1]) == len(sol.t) - 1
+    # ... the fixed-point posterior can be evaluated between ITS stored points too, but it has forgotten the measurements in
+    # between (that is the memory it saves): exact at its own save_at points, only close in between
+    both = np.concatenate([save_at, ts[[1, 2, 4]]])
+    dense3, _ = stats.offgrid_marginals_searchsorted(ts=both, solution=fp, solver=fixedpoint)
+    assert np.array_equal(dense3[: len(save_at)], fp.u)
+    assert 1e-8 < relmax(dense3[len(save_at):], ref[[1, 2, 4], 0]) < 1e-2
+    with pytest.raises(ValueError):
+        stats.offgrid_marginals_searchsorted(ts=np.array([1.5]), solution=sol, solver=smoother)
+    with pytest.raises(RuntimeError):
+        ivpsolve.solve_adaptive_save_every_step(vf, init, t0=0.0, t1=1.0, dt0=0.01, max_steps=5,
+                                                adaptive_solver=ivpsolve.adaptive(smoother, atol=tol, rtol=tol))
+
+
+@pytest.mark.parametrize("method", ["ts0-2", "ts0-4"])
+def test_solve_via_interpolate_like_the_reference_test(hip_lib, method):
+    """Second half of the reference's test (tests/test_ivpsolvers.py:19-24,31-52): `solve_via_interpolate` against an
+    independent Runge-Kutta solver on the logistic ODE within sqrt(tol) (scipy in place of diffrax), `aux["u0_solve"]` present;
+    and it agrees with `solve` (fixed-point smoother) far inside that tolerance."""
+    from odecheckpts import ivps
+    from odecheckpts import ivpsolvers as l3
+
+    vf, u0, time_span, args = ivps.logistic()
+    dt0, atol, rtol = 0.1, 1e-3, 1e-3
+    save_at = np.linspace(*time_span, num=5)
+    solution1, aux1 = l3.solve_via_interpolate(method, vf, u0[0], save_at, dt0=dt0, atol=atol, rtol=rtol)(u0, args)
+    assert "u0_solve" in aux1 and "solution" in aux1
+    truth = scipy_truth(vf.bind(args), u0[0], save_at)
+    assert solution1.shape == truth.shape == (5, 1)
+    assert np.allclose(solution1, truth, atol=np.sqrt(atol), rtol=np.sqrt(rtol))
+    solution2, _ = l3.solve(method, vf, u0[0], save_at, dt0=dt0, atol=atol, rtol=rtol)(u0, args)
+    assert np.allclose(solution1, solution2, atol=0.1 * np.sqrt(atol), rtol=0.1 * np.sqrt(rtol))
+
+
+def test_markov_sample_reverse(hip_lib):
+    """Joint samples of the fixed-point posterior (measure.py:66-75): zero base samples give the smoothed means; a base sample
+    in the terminal entry alone travels through the chain of backward transitions exactly as in the oracle; the sample
+    covariance at a checkpoint matches the oracle's smoothing marginal."""
+    vf, tcs, cfg, acfg, tol = _brusselator_case(3)
+    cfg = po.SolverConfig(nu=3, model="isotropic", correction="ts0", strategy="fixedpoint", calibration="none")
+    solver = ivpsolvers.solver(ivpsolvers.strategy_fixedpoint(ivpsolvers.prior_ibm(3), ivpsolvers.correction_ts0()))
+    save_at = np.linspace(0.0, 1.0, 5)
+    sol = ivpsolve.solve_adaptive_save_at(vf, solver.initial_condition(tcs, 1.0), save_at=save_at, dt0=0.01,
+                                          adaptive_solver=ivpsolve.adaptive(solver, atol=tol, rtol=tol))
+    osol = po.solve_adaptive_save_at(cfg, acfg, oracle_problem(vf), po.initial_state(cfg, tcs, 0.0), save_at, 0.01)
+    sm = po.markov_marginals_reverse(cfg, osol)
+    seq = stats.markov_select_terminal(sol.posterior)
+    batch = sol.posterior.batch
+    T, n, d = len(save_at), 4, vf.d
+    nf = sol.posterior.num_filled
+    zero = batch.sample_checkpoints(nf, np.zeros((1, 1, T, n, d)))[0, 0]
+    assert relmax(zero[:, 0], sm[:, 0]) < 1e-9
+    rng = np.random.default_rng(5)
+    eps = np.zeros((1, 1, T, n, d))
+    eps[0, 0, -1] = rng.standard_normal((n, d))
+    got = batch.sample_checkpoints(nf, eps)[0, 0]
+    want = po.markov_sample_reverse(cfg, osol, eps[0, 0])
+    assert np.max(np.abs((got - zero) - (want - sm))) <= 1e-6 * np.max(np.abs(want - sm))
+    # reference call shape and statistics
+    S = 20000
+    (qoi, samples), (init_qoi, init_s) = stats.markov_sample(7, seq, shape=(S,), reverse=True)
+    assert qoi.shape == (S, T - 1, d) and samples.shape == (S, T - 1, n, d) and init_qoi.shape == (S, d) and init_s.shape == (S, n, d)
+    full = np.concatenate([qoi, init_qoi[:, None, :]], axis=1)  # measure.py:73
+    chols = po.markov_marginal_chols_reverse(cfg, osol)
+    for i in (1, T - 1):
+        var_ref = (chols[i] @ chols[i].T)[0, 0]  # isotropic: every component of u has this variance
+        assert np.max(np.abs(full[:, i].mean(axis=0) - sm[i, 0])) < 6.0 * np.sqrt(var_ref / S)
+        assert abs(full[:, i].var(axis=0).mean() / var_ref - 1.0) < 0.05

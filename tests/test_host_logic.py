@@ -166,8 +166,13 @@ def test_odecheckpts_solve_surface():
     fn = l3.solve("ts0-2", vf, u0[0], save_at, dt0=0.1, atol=1e-3, rtol=1e-3)
     with pytest.raises(ValueError):
         fn(u0[0], args)  # tuple expected
+    with pytest.raises(ValueError):
+        l3.solve_via_interpolate("ts1-2", vf, u0[0], save_at, dt0=0.1, atol=1e-3, rtol=1e-3)
+    fn2 = l3.solve_via_interpolate("ts0-2", vf, u0[0], save_at, dt0=0.1, atol=1e-3, rtol=1e-3)
+    with pytest.raises(ValueError):
+        fn2(u0[0], args)  # tuple expected
     with pytest.raises(NotImplementedError):
-        l3.solve_via_interpolate("ts0-2", vf, u0[0], save_at, dt0=0.1, atol=1e-3, rtol=1e-3)
+        l3.solve_diffrax("tsit5", vf, u0[0], save_at, dt0=0.1, atol=1e-3, rtol=1e-3)
     for name in ("rigid_body", "pleiades_1st", "pleiades_2nd", "van_der_pol", "logistic"):
         out = getattr(ivps, name)()
         assert out[0].d == np.asarray(out[1][0]).shape[-1]
