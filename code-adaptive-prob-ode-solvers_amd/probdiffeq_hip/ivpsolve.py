@@ -345,7 +345,7 @@ def _save_every_step_smoother(vector_field, init, t0b, t1b, adaptive_solver, dt0
 
 
 def solve_adaptive_save_every_step(vector_field, initial_condition: InitialCondition, t0, t1,
-                                   adaptive_solver: AdaptiveSolver, dt0, *, device=None, max_steps=4096):
+                                   adaptive_solver: AdaptiveSolver, dt0, *, device=None, max_steps=16384):
     """Adaptive solve that returns every accepted step (vdp.py:77-79). Ragged over the batch: returns a
     Solution for an unbatched initial condition and a list of Solutions otherwise. Meant for small
     problems: each accepted batched step copies the means back to the host (strategy_filter) or stores the step with its

@@ -127,3 +127,39 @@ def test_markov_sample_reverse(hip_lib):
         var_ref = (chols[i] @ chols[i].T)[0, 0]  # isotropic: every component of u has this variance
         assert np.max(np.abs(full[:, i].mean(axis=0) - sm[i, 0])) < 6.0 * np.sqrt(var_ref / S)
         assert abs(full[:, i].var(axis=0).mean() / var_ref - 1.0) < 0.05
+
+
+def test_workprecision_result_files_have_the_reference_schema(hip_lib, golden, tmp_path):
+    """experiments/workprec_simple.py writes what the reference's run_simple.py writes (run_simple.py:128-136,
+    206-215) -- a pickled dict label -> {list_of_args, length_of_longest_vector, work_min, work_mean, work_std, precision} plus
+    the three array files -- and the numbers in it land on the reference's committed curve (data_results.npy): the RMSE of
+    TS0(2) / TS0(4) at the same tolerances, the number of stored steps of the store-everything variant."""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("workprec_simple", os.path.join(root, "experiments", "workprec_simple.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.main(["--start", "3", "--stop", "6", "--repeats", "2", "--outdir", str(tmp_path)])
+    res = np.load(tmp_path / "data_results.npy", allow_pickle=True).item()
+    g = golden["rigid_body"]
+    ref_labels = sorted({k.split("__")[0] for k in g.files if "__" in k and "probdiffeq" in k})
+    assert set(ref_labels) <= set(res.keys())
+    for label in ref_labels:
+        rec = res[label]
+        assert set(rec.keys()) == {"list_of_args", "length_of_longest_vector", "work_min", "work_mean", "work_std", "precision"}
+        k = len(rec["list_of_args"])
+        assert k == (3 if "loop" in label else 2) and all(len(rec[key]) == k for key in rec)
+        assert np.allclose(rec["list_of_args"], g[f"{label}__list_of_args"][:k])
+        assert np.all(rec["work_min"] > 0) and np.all(rec["work_min"] <= rec["work_mean"] + 1e-15)
+        # same algorithm, same tolerances: the precision curve of the reference's committed run
+        assert np.allclose(rec["precision"], g[f"{label}__precision"][:k], rtol=0.2), (label, rec["precision"])
+        if "step" in label:  # stored steps + 1 of the store-everything smoother (222, 484 in the reference's file)
+            assert np.allclose(rec["length_of_longest_vector"], g[f"{label}__length_of_longest_vector"][:k], rtol=0.05)  # (215 and 485 here: a loose-tolerance run is decision-sensitive)
+        else:
+            assert np.all(rec["length_of_longest_vector"] == 5)
+    assert np.array_equal(np.load(tmp_path / "data_checkpoints.npy"), g["checkpoints"])
+    ts, ys = np.load(tmp_path / "data_ts.npy"), np.load(tmp_path / "data_ys.npy")
+    assert ys.shape == (len(ts), 3) and ts[0] == 0.0 and ts[-1] == 50.0
+    assert any("one batch" in k for k in res)
