@@ -366,6 +366,7 @@ int pnode_create(const pnode_config* cfg, pnode_batch** out) {
     ALLOC(v.sigma, NS * B);
     ALLOC(v.ck_mean, B * Kc * n * d);
     ALLOC(v.ck_steps, B * Kc);
+    if ((cfg->reserved & PNODE_FLAG_CHECKPOINT_FACTORS) && !v.fixedpoint) ALLOC(v.ck_fac, B * Kc * D * D);
     ALLOC(v.M, B * v.mr_rows * D * D);
     ALLOC(v.R, B * v.mr_rows * D * D);
     ALLOC(v.act, B);
@@ -640,9 +641,17 @@ static int run_interp(pnode_batch* h, const double* t, const int32_t* slot, bool
       h->hFp1[b] = FpArg{a.t1 - a.t, 3, 4, 0, act, 0, 0};     // t -> t1 from the identity
     }
     dense_fp_launch_interp(h->dn, h->dIargs, h->zFp0, h->zFp1, h->dK, h->stream);
-  } else if (h->dense)
+  } else if (h->dense) {
     dense_launch_interp(h->dn, h->dIargs, h->dK, h->stream);
-  else
+    if (h->dn.ck_fac) {  // covariance factor at the checkpoint: a time update without a measurement, on the generic kernels
+      for (size_t b = 0; b < B; ++b) {
+        const InterpArg& a = h->hIargs[b];
+        h->hArgs[b] = StepArg{at_step ? 1.0 : a.t - a.t0, a.t0, a.s0, a.s0, (a.ckpt >= 0 && !a.at_step) ? 1 : 0, 0};
+      }
+      HIP_TRY(hipMemcpyAsync(h->dArgs, h->hArgs, B * sizeof(StepArg), hipMemcpyHostToDevice, h->stream));
+      dense_launch_checkpoint_factors(h->dn, h->dIargs, h->dArgs, h->dK, h->stream);
+    }
+  } else
     iso_launch_interp(h->iso, h->dIargs, h->dK, h->stream);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1087,6 +1096,29 @@ int pnode_read_checkpoint_means(pnode_batch* h, double* out) {
   const size_t cnt = size_t(h->cfg.batch) * h->cfg.num_checkpoints * h->n * h->cfg.d;
   if (cnt == 0) return PNODE_OK;
   HIP_TRY(hipMemcpy(out, h->dense ? h->dn.ck_mean : h->iso.ck_mean, cnt * sizeof(double), hipMemcpyDeviceToHost));
+  return PNODE_OK;
+}
+
+int pnode_read_checkpoint_factors(pnode_batch* h, double* out) {
+  if (!h || !out) return fail(PNODE_EINVAL, "null argument");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  const size_t B = h->cfg.batch, K = h->cfg.num_checkpoints;
+  const size_t m = h->dense ? size_t(h->D) : size_t(h->n);
+  const double* src = h->dense ? h->dn.ck_fac : h->iso.ck_fac;
+  if (!src) return fail(PNODE_ESTATE, "checkpoint factors were not requested at creation (PNODE_FLAG_CHECKPOINT_FACTORS) or the "
+                                     "strategy keeps backward transitions instead (dense fixedpoint)");
+  const size_t cnt = B * K * m * m;
+  if (cnt == 0) return PNODE_OK;
+  if (!h->dense) {
+    HIP_TRY(hipMemcpy(out, src, cnt * sizeof(double), hipMemcpyDeviceToHost));
+    return PNODE_OK;
+  }
+  std::vector<double> tmp(m * m);
+  for (size_t i = 0; i < B * K; ++i) {  // stored as L (Sigma = L L^T): hand out R = L^T like pnode_read_factor
+    HIP_TRY(hipMemcpy(tmp.data(), src + i * m * m, m * m * sizeof(double), hipMemcpyDeviceToHost));
+    for (size_t r = 0; r < m; ++r)
+      for (size_t c = 0; c < m; ++c) out[i * m * m + r * m + c] = tmp[c * m + r];
+  }
   return PNODE_OK;
 }
 

@@ -110,6 +110,12 @@ __device__ __forceinline__ double fast_rcp(double x) {
   return y;
 }
 
+// Element index of L[row][col] in the strip ("tiled") order of the MFMA path (pnode_mfma_common.hpp), run-time DT = D / 16.
+__host__ __device__ inline size_t tiled_index_rt(int row, int col, int DT) {
+  const int s = row >> 4, r = row & 15, T = col >> 6, g = (col >> 4) & 3, e = col & 15;
+  return ((size_t(s) * (2 * DT) + 8 * T + (e >> 1)) * 64 + r + 16 * g) * 2 + (e & 1);
+}
+
 // Rotate the row x (length N) into the upper-triangular R (N x N) with Givens rotations:
 // afterwards R^T R (new) = R^T R (old) + x^T x. Orthogonal transformations only.
 template <int N>

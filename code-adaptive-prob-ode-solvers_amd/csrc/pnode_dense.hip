@@ -177,11 +177,13 @@ __global__ __launch_bounds__(kThreads) void dense_lq_input_kernel(DenseView v, c
   double* Mt = v.M + size_t(b) * v.mr_rows * D * D;
   double* T = v.R + size_t(b) * v.mr_rows * D * D;
   if (blockIdx.x == 0 && threadIdx.x == 0) v.act[b] = 1;
+  const bool tiled = v.u_tiled_now != 0;  // (checkpoint factors of an MFMA-path handle: the state factor is in strip order)
   for (int r = blockIdx.x; r < D; r += gridDim.x) {
     const int i = r / d, q = r % d;
     for (int c = threadIdx.x; c < D; c += kThreads) {
       double acc = 0.0;
-      for (int kk = i; kk < n; ++kk) acc += K.a[i][kk] * pinv[kk] * L[size_t(kk * d + q) * D + c];
+      for (int kk = i; kk < n; ++kk)
+        acc += K.a[i][kk] * pinv[kk] * L[tiled ? tiled_index_rt(kk * d + q, c, D / 16) : size_t(kk * d + q) * D + c];
       Mt[size_t(r) * D + c] = acc;
       const int j = c / d, q2 = c % d;
       T[size_t(r) * D + c] = (q2 == q && j <= i) ? sigma * K.qsT[j][i] : 0.0;
@@ -338,6 +340,39 @@ __global__ __launch_bounds__(kThreads) void dense_correct_kernel(DenseView v, co
   }
 }
 
+// Covariance factors at the save_at points of the dense FILTER (solution.posterior of the reference carries one Cholesky factor
+// per checkpoint: /root/reference/src/odecheckpts/ivpsolvers.py:71-81, experiments/4_brusselator/run.py:136-138).
+//   prepare: sig_new <- output scale of STEP_FROM (the scale the interpolation uses);
+//   store  : at_step -> copy L of STEP_FROM (de-tiled for the MFMA path); otherwise L^-(t) = diag(p) T with T the LQ factor of
+//            [sigma chol(Qbar) (x) I | (Abar P^-1 (x) I) L(INTERP_FROM)] that dense_lq_input_kernel + dense_lq_kernel left in v.R.
+__global__ void dense_ckfac_prepare_kernel(DenseView v, const InterpArg* __restrict__ args) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= v.B) return;
+  const InterpArg a = args[b];
+  if (a.ckpt >= 0 && !a.at_step) v.sig_new[b] = v.sigma[size_t(a.s1) * v.B + b];
+}
+
+__global__ __launch_bounds__(kThreads) void dense_ckfac_store_kernel(DenseView v, const InterpArg* __restrict__ args,
+                                                                     const IwpConst* __restrict__ Kc) {
+  const int b = blockIdx.y;
+  const InterpArg a = args[b];
+  if (a.ckpt < 0) return;
+  const int d = v.d, n = v.n, D = v.D;
+  double* out = v.ck_fac + (size_t(b) * v.K + a.ckpt) * D * D;
+  if (a.at_step) {
+    const double* L = v.U + (size_t(a.s1) * v.B + b) * D * D;
+    const bool tiled = v.u_tiled_now != 0;
+    for (int r = blockIdx.x; r < D; r += gridDim.x)
+      for (int c = threadIdx.x; c < D; c += kThreads) out[size_t(r) * D + c] = L[tiled ? tiled_index_rt(r, c, D / 16) : size_t(r) * D + c];
+    return;
+  }
+  double p[kMaxN], pinv[kMaxN];
+  preconditioner_rt(n, a.t - a.t0, *Kc, p, pinv);
+  const double* T = v.R + size_t(b) * v.mr_rows * D * D;
+  for (int r = blockIdx.x; r < D; r += gridDim.x)
+    for (int c = threadIdx.x; c < D; c += kThreads) out[size_t(r) * D + c] = (c <= r) ? p[r / d] * T[size_t(r) * D + c] : 0.0;
+}
+
 // Filter checkpoint: the solution at t is the prediction of the mean from INTERP_FROM (Chapman-
 // Kolmogorov: predicting t0 -> t -> t' equals t0 -> t', so INTERP_FROM itself is left untouched).
 __global__ __launch_bounds__(kThreads) void dense_interp_kernel(DenseView v, const InterpArg* __restrict__ args,
@@ -421,6 +456,17 @@ void dense_launch_lq_generic(const DenseView& v, int rows_total, hipStream_t s) 
 
 void dense_launch_interp(const DenseView& v, const InterpArg* args, const IwpConst* K, hipStream_t s) {
   hipLaunchKernelGGL(dense_interp_kernel, dim3(v.B), dim3(kThreads), 0, s, v, args, K);
+}
+
+// `pargs`: per trajectory {dt = t - t0, src = INTERP_FROM slot, active = interpolated checkpoint} (built by the caller).
+void dense_launch_checkpoint_factors(const DenseView& v_, const InterpArg* args, const StepArg* pargs, const IwpConst* K, hipStream_t s) {
+  DenseView v = v_;
+  v.u_tiled_now = dense_state_factor_tiled(v_) ? 1 : 0;
+  hipLaunchKernelGGL(dense_ckfac_prepare_kernel, dim3((v.B + 255) / 256), dim3(256), 0, s, v, args);
+  const int rows_per = v.D < 64 ? v.D : 64;
+  hipLaunchKernelGGL(dense_lq_input_kernel, dim3(rows_per, v.B), dim3(kThreads), 0, s, v, pargs, K);
+  hipLaunchKernelGGL(dense_lq_kernel, dim3(v.B), dim3(kThreads), 0, s, v, v.D);
+  hipLaunchKernelGGL(dense_ckfac_store_kernel, dim3(rows_per, v.B), dim3(kThreads), 0, s, v, args, K);
 }
 
 }  // namespace pnode

@@ -54,6 +54,8 @@ struct DenseView {
   const double* user_J;  // PNODE_VF_USER: [B][d][k*d]
   double* errnorm;  // [B]
   double* ck_mean;  // [B][K][n][d]
+  double* ck_fac;   // [B][K][D][D] L at the save_at points of the filter (row-major, Sigma = L L^T); null unless requested
+  int u_tiled_now;  // set by the checkpoint-factor launcher only: v.U is in the strip order of the MFMA path
   int64_t* ck_steps;
   // per-attempt scratch
   double* M;     // [B][D][D]  QR input, (A L)^T in preconditioned coordinates
@@ -116,6 +118,7 @@ void dense_launch_mfma_begin(const DenseView& v, const StepArg* args, const IwpC
 void dense_launch_mfma_tail(const DenseView& v, const StepArg* args, const IwpConst* K, hipStream_t s,
                             const PhaseEvents* ev);
 void dense_launch_interp(const DenseView& v, const InterpArg* args, const IwpConst* K, hipStream_t s);
+void dense_launch_checkpoint_factors(const DenseView& v, const InterpArg* args, const StepArg* pargs, const IwpConst* K, hipStream_t s);
 // dense fixed-point smoother (generic kernels, pnode_dense_fp.hip)
 void dense_fp_launch_step_tail(const DenseView& v, const FpArg* fargs, const IwpConst* K, hipStream_t s);
 void dense_fp_launch_interp(const DenseView& v, const InterpArg* iargs, const FpArg* op1, const FpArg* op2, const IwpConst* K,

@@ -23,7 +23,7 @@ SYMBOLS = (
     "pnode_last_error pnode_version pnode_device_count pnode_create pnode_destroy pnode_set_initial "
     "pnode_set_tolerances pnode_attempt_step pnode_user_extrapolate pnode_user_set_vf pnode_commit pnode_interpolate pnode_checkpoint_at_step "
     "pnode_solve_fixed_grid pnode_solve_adaptive_save_at pnode_solve_adaptive_save_at_device pnode_read_mean pnode_read_time pnode_read_output_scale pnode_read_factor "
-    "pnode_read_checkpoint_means pnode_smooth_checkpoint_means pnode_last_step_ms pnode_set_phase_timing "
+    "pnode_read_checkpoint_means pnode_read_checkpoint_factors pnode_smooth_checkpoint_means pnode_last_step_ms pnode_set_phase_timing "
     "pnode_last_phase_ms pnode_set_generic_path pnode_stream pnode_lq_schedule pnode_advance_device"
 ).split()
 
@@ -109,6 +109,7 @@ def load_library():
     lib.pnode_read_output_scale.argtypes = [vp, C.c_int32, dp]
     lib.pnode_read_factor.argtypes = [vp, C.c_int32, dp]
     lib.pnode_read_checkpoint_means.argtypes = [vp, dp]
+    lib.pnode_read_checkpoint_factors.argtypes = [vp, dp]
     lib.pnode_smooth_checkpoint_means.argtypes = [vp, i32p, dp]
     lib.pnode_last_step_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.pnode_set_phase_timing.argtypes = [vp, C.c_int32]
@@ -151,7 +152,7 @@ class Batch:
     """Owner of one `pnode_batch` handle: B independent IVPs resident on one GPU."""
 
     def __init__(self, *, batch, d, nu, ode_order, model, correction, strategy, calibration, vf_id,
-                 vf_params=None, num_checkpoints=0, device=None):
+                 vf_params=None, num_checkpoints=0, device=None, checkpoint_factors=False):
         lib = load_library()
         self._lib = lib
         self._h = None
@@ -172,7 +173,7 @@ class Batch:
         cfg = PnodeConfig(
             batch=batch, d=d, nu=nu, ode_order=ode_order, model=MODEL[model], correction=CORRECTION[correction],
             strategy=STRATEGY[strategy], calibration=CALIBRATION[calibration], vf_id=vf_id, num_vf_params=nprm,
-            vf_params_per_trajectory=per_traj, num_checkpoints=num_checkpoints, device=device, reserved=0,
+            vf_params_per_trajectory=per_traj, num_checkpoints=num_checkpoints, device=device, reserved=1 if checkpoint_factors else 0,
             vf_params=_dp(prm) if prm is not None else None,
         )
         h = C.c_void_p()
@@ -334,6 +335,13 @@ class Batch:
     def read_checkpoint_means(self):
         out = np.zeros((self.B, self.K, self.n, self.d))
         _check(self._lib.pnode_read_checkpoint_means(self._h, _dp(out)))
+        return out
+
+    def read_checkpoint_factors(self):
+        """Upper factors R (B, K, m, m) with Sigma = R^T R at the checkpoints (m = n isotropic, m = n d dense filter)."""
+        m = self.D if self.model == "dense" else self.n
+        out = np.zeros((self.B, self.K, m, m))
+        _check(self._lib.pnode_read_checkpoint_factors(self._h, _dp(out)))
         return out
 
     def smooth_checkpoint_means(self, num_filled):

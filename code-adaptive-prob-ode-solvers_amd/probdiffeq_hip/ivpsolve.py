@@ -83,6 +83,14 @@ class Posterior:
     init_means: np.ndarray = None  # (B, n, d) mean of the initial condition
     index: int = None  # set when this object describes ONE trajectory of a batched solve
 
+    def checkpoint_factors(self):
+        """Upper covariance factors R at the checkpoints after t0 (Sigma = R^T R; isotropic: Sigma = R^T R (x) I): what
+        `solution.posterior` of the reference carries per save_at point (ivpsolvers.py:71-81). Filter: the filtering
+        covariance; fixedpoint (isotropic): the one-step-smoothed one of the checkpoint interpolation. (B, K, m, m), or
+        (K, m, m) for one trajectory."""
+        f = self.batch.read_checkpoint_factors()
+        return f if self.index is None else f[self.index]
+
 
 @dataclasses.dataclass
 class Solution:
@@ -102,6 +110,10 @@ def _as_vf(vf):
             "Python callable cannot run inside the HIP step kernel."
         )
     return vf
+
+
+# the dense filter stores a D x D covariance factor per save_at point when that fits this many bytes (else means only)
+CHECKPOINT_FACTOR_BYTES = 4 << 30
 
 
 def _make_batch(vf, init: InitialCondition, solver: Solver, num_checkpoints, device=None):
@@ -128,6 +140,8 @@ def _make_batch(vf, init: InitialCondition, solver: Solver, num_checkpoints, dev
         batch=B, d=d, nu=st.prior.num_derivatives, ode_order=st.correction.ode_order, model=st.model,
         correction=st.correction.kind, strategy=kind, calibration=solver.calibration, vf_id=vf.vf_id,
         vf_params=prm, num_checkpoints=num_checkpoints, device=device,
+        checkpoint_factors=(st.model == "dense" and kind == "filter"
+                            and 8 * B * num_checkpoints * (n * d) ** 2 <= CHECKPOINT_FACTOR_BYTES),
     )
     return batch
 
@@ -275,6 +289,7 @@ def solve_adaptive_save_at(vector_field, initial_condition: InitialCondition, sa
             means[b, cursor[b]:] = np.nan
     sol = _finish(means, init, solver.strategy.kind, batch, sa if sa.ndim == 1 else sa_b, num_steps, loop,
                   not init.batched)
+    sol.posterior.index = None if init.batched else 0
     if solver.strategy.kind == "fixedpoint":
         sol.posterior.grid = sa_b
         sol.posterior.num_filled = np.minimum(cursor - 1, K).astype(np.int32)

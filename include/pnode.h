@@ -63,6 +63,11 @@ extern "C" {
 
 #define PNODE_MAX_VF_PARAMS 8
 
+/* pnode_config.reserved, bit 0: the dense filter also stores the covariance factor at every save_at point ([B][K][D][D]
+ * doubles) -- solution.posterior of the reference carries one per checkpoint (src/odecheckpts/ivpsolvers.py:71-81,
+ * experiments/4_brusselator/run.py:136-138). The isotropic model always stores its (n x n) factors. */
+#define PNODE_FLAG_CHECKPOINT_FACTORS 1
+
 typedef struct pnode_config {
   int32_t batch;            /* B: number of independent IVPs on this GPU                     */
   int32_t d;                /* ODE dimension                                                 */
@@ -77,7 +82,7 @@ typedef struct pnode_config {
   int32_t vf_params_per_trajectory; /* 0: vf_params is [P] shared, 1: [B][P]                 */
   int32_t num_checkpoints;  /* capacity K of the checkpoint store (save_at points after t0)  */
   int32_t device;           /* HIP device ordinal                                            */
-  int32_t reserved;
+  int32_t reserved;         /* flags: PNODE_FLAG_*                                           */
   const double* vf_params;  /* host pointer, copied at creation                              */
 } pnode_config;
 
@@ -177,6 +182,10 @@ int pnode_read_output_scale(pnode_batch* h, int32_t which, double* out /* [B] */
 int pnode_read_factor(pnode_batch* h, int32_t which, double* out);
 /* Checkpoint store: means [B][K][nu+1][d]; num_steps at each checkpoint [B][K]. */
 int pnode_read_checkpoint_means(pnode_batch* h, double* out);
+/* Covariance factors at the checkpoints: out [B][K][m][m], a factor R with Sigma = R^T R (upper triangular for the isotropic
+ * model and for interpolated checkpoints, a general square factor where a checkpoint coincides with a step; m = nu+1 for the isotropic
+ * model, Sigma = R^T R (x) I_d; m = (nu+1) d for the dense filter created with PNODE_FLAG_CHECKPOINT_FACTORS). */
+int pnode_read_checkpoint_factors(pnode_batch* h, double* out);
 /* Backward pass over the stored checkpoint transitions (fixedpoint only):
  * stats.markov_select_terminal + stats.markov_marginals(reverse=True) — ivpsolvers.py:80-81.
  * num_filled[b] = number of checkpoints stored for trajectory b; the terminal marginal is the

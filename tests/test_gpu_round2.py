@@ -166,3 +166,46 @@ def test_overflow_turns_into_nan_like_the_oracle(hip_lib, golden):
     assert relmax(u[:first][tame], ou[:first][tame]) < 1e-8
     assert np.all(np.isnan(u[first + 1:])) and np.all(np.isnan(ou[first + 1:]))
     assert np.any(np.isnan(u))  # the reference's assertion
+
+
+@pytest.mark.parametrize("case", ["small_vdp2", "generic_rigid", "mfma_bruss16", "large_bruss16", "iso_bruss8"])
+def test_checkpoint_covariance_factors_of_the_filter(hip_lib, case, monkeypatch):
+    """solution.posterior of the reference carries a Cholesky factor per save_at point (ivpsolvers.py:71-81, run.py:136-138):
+    the filter's covariance at every checkpoint (interpolated ones: a time update without a measurement; corner ones: the
+    state itself, whose factor is not triangular: the measurement update is a projector) against the oracle, R^T R to 1e-7, on every dense device path (the MFMA path keeps its state factor in strip
+    order and de-tiles it for the store) and for the isotropic model."""
+    from probdiffeq_hip import _backend
+
+    model, corr = "dense", "ts1"
+    if case == "small_vdp2":
+        vf, nu, u0s, tol, save_at, dt0 = V.van_der_pol_order2(5.0), 4, [np.array([2.0]), np.array([0.0])], 1e-4, np.linspace(0, 2.0, 5), 0.01
+    elif case == "generic_rigid":
+        vf, nu, u0s, tol, save_at, dt0 = V.rigid_body(), 3, [np.array([1.0, 0.0, 0.9])], 1e-4, np.linspace(0, 4.0, 5), 0.1
+        monkeypatch.setattr(_backend, "dense_path", 1)
+    elif case == "iso_bruss8":
+        model, corr = "isotropic", "ts0"
+        vf, nu, u0s, tol, save_at, dt0 = V.brusselator(8), 3, [brusselator_y0(8)], 1e-5, np.linspace(0, 0.5, 4), 0.01
+    else:
+        vf, nu, u0s, tol, save_at, dt0 = V.brusselator(16), 3, [brusselator_y0(16)], 1e-4, np.linspace(0, 0.3, 4), 0.01
+        if case.startswith("large"):
+            monkeypatch.setattr(_backend, "dense_path", 2)
+    impl.select(model, ode_shape=(vf.d,))
+    correction = getattr(ivpsolvers, f"correction_{corr}")(ode_order=vf.ode_order)
+    solver = ivpsolvers.solver_dynamic(ivpsolvers.strategy_filter(ivpsolvers.prior_ibm(nu), correction))
+    tcs = tcoeffs(vf, u0s, nu)
+    # a save_at point that coincides with an accepted step exercises the corner branch: take it from a first solve
+    first = ivpsolve.solve_adaptive_save_every_step(vf, solver.initial_condition(tcs, 1.0), t0=save_at[0], t1=save_at[-1], dt0=dt0,
+                                                    adaptive_solver=ivpsolve.adaptive(solver, atol=tol, rtol=tol))
+    save_at = np.sort(np.append(save_at, first.t[3]))
+    sol = ivpsolve.solve_adaptive_save_at(vf, solver.initial_condition(tcs, 1.0), save_at=save_at, dt0=dt0,
+                                          adaptive_solver=ivpsolve.adaptive(solver, atol=tol, rtol=tol))
+    cfg = po.SolverConfig(nu=nu, model=model, correction=corr, strategy="filter", calibration="dynamic")
+    osol = po.solve_adaptive_save_at(cfg, po.AdaptiveConfig(tol, tol), oracle_problem(vf), po.initial_state(cfg, tcs, 0.0), save_at, dt0)
+    assert np.array_equal(sol.num_steps, osol.num_steps)
+    R = sol.posterior.checkpoint_factors()
+    m = (nu + 1) * (vf.d if model == "dense" else 1)
+    assert R.shape == (len(save_at) - 1, m, m)
+    for i in range(1, len(save_at)):
+        cov_ref = osol.states[i].chol @ osol.states[i].chol.T
+        cov = R[i - 1].T @ R[i - 1]
+        assert np.max(np.abs(cov - cov_ref)) <= 1e-7 * np.max(np.abs(cov_ref)), (case, i)
