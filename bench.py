@@ -61,9 +61,9 @@ def algorithmic_flops_lq(D):
 
 def measured_traffic(kernel_prefix, batch):
     """HBM bytes per launch of the dominant kernel from the committed PMC summary
-    (profiles/r01_pmc_summary.json, produced on an MI355X by scripts/collect_profile.sh with separate
+    (profiles/r02_pmc_summary.json, produced on an MI355X by scripts/collect_profile.sh with separate
     --pmc passes; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md), scaled to this batch."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    path = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
     try:
         data = json.load(open(path))
     except OSError:
@@ -75,19 +75,34 @@ def measured_traffic(kernel_prefix, batch):
     return total * batch / 1024.0 if total > 0.0 else None  # the profile run uses 1024 trajectories
 
 
-def cpu_baseline(seconds=15.0):
-    """The oracle ("port") timed on this host's cores on a bounded sample of the same workload:
-    oracle/pn_oracle_c.c (C restatement of oracle/pn_oracle.py, checked against it in tests/test_oracle_c.py),
-    OpenMP with one trajectory per thread, every thread running the adaptive loop for `seconds`."""
-    import ctypes as C
-
+def _granted_cpus():
+    """Cores this process may actually use: the affinity mask, capped by the cgroup CPU quota where one is set."""
     try:
-        threads = len(os.sched_getaffinity(0))
+        aff = len(os.sched_getaffinity(0))
     except AttributeError:
-        threads = os.cpu_count() or 1
-    # a 1-GPU box grants a CPU share of 16 cores whatever the affinity mask says; more threads only contend
-    threads = int(os.environ.get("PNODE_CPU_THREADS", min(threads, 16)))
-    vf, tcs = problem_batch(threads, 0, 1024)
+        aff = os.cpu_count() or 1
+    quota = None
+    try:
+        mx, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if mx != "max":
+            quota = max(1, int(float(mx) / float(period)))
+    except (OSError, ValueError):
+        pass
+    return aff, quota
+
+
+def cpu_baseline(seconds=5.0, repeats=3):
+    """The oracle ("port") timed on this host's cores on a bounded sample of the same workload (BASELINE.md section 2):
+    oracle/pn_oracle_c.c (C restatement of oracle/pn_oracle.py, checked against it in tests/test_oracle_c.py) with its
+    LAPACK / BLAS back end (blocked dgeqrf, dgemm, dtrsm of the OpenBLAS that scipy ships, one BLAS thread per OpenMP thread),
+    OpenMP with one trajectory per thread on every granted core, every thread running the adaptive loop for `seconds`; one
+    warm-up, then the best of `repeats` runs; the single-core figure next to it."""
+    import ctypes as C
+    import glob
+
+    aff, quota = _granted_cpus()
+    threads = int(os.environ.get("PNODE_CPU_THREADS", min(aff, quota) if quota else aff))
+    vf, tcs = problem_batch(max(threads, 1), 0, 1024)
     tc = np.ascontiguousarray(np.stack(tcs, axis=1))
     path = os.path.join(ROOT, "oracle", "libpn_oracle_c.so")
     if os.path.exists(path):
@@ -96,13 +111,34 @@ def cpu_baseline(seconds=15.0):
         lib.pnoc_bench_brusselator.restype = C.c_double
         lib.pnoc_bench_brusselator.argtypes = [C.c_int, C.c_int, C.c_int, dp, C.c_double, C.c_double, C.c_double, C.c_int,
                                                C.POINTER(C.c_long), C.POINTER(C.c_long)]
-        acc, att = C.c_long(), C.c_long()
-        el = lib.pnoc_bench_brusselator(N_SPATIAL, NU, threads, tc.ctypes.data_as(dp), TOL, DT0, seconds, threads,
-                                        C.byref(acc), C.byref(att))
-        return {"value": acc.value / el, "unit": "accepted steps/s", "cores": int(threads), "kind": "port",
-                "sample": f"oracle/pn_oracle_c.c (OpenMP, one trajectory per thread), {threads} trajectories of the same "
-                          f"batch for {el:.1f}s: {acc.value} accepted / {att.value} attempted steps; "
-                          f"{acc.value / el / threads:.1f} steps/s per core; host reports {os.cpu_count()} cpus"}
+        lib.pnoc_use_lapack.argtypes = [C.c_char_p]
+        backend = "plain loops"
+        try:
+            import scipy
+
+            hits = glob.glob(os.path.join(os.path.dirname(scipy.__file__), "..", "scipy.libs", "libscipy_openblas*.so"))
+            if hits and lib.pnoc_use_lapack(hits[0].encode()) == 1:
+                backend = "LAPACK dgeqrf + BLAS dgemm/dtrsm (scipy's OpenBLAS, 1 BLAS thread per OpenMP thread)"
+        except ImportError:
+            pass
+
+        def run(nthreads, secs):
+            acc, att = C.c_long(), C.c_long()
+            el = lib.pnoc_bench_brusselator(N_SPATIAL, NU, nthreads, tc.ctypes.data_as(dp), TOL, DT0, secs, nthreads,
+                                            C.byref(acc), C.byref(att))
+            return acc.value / el, att.value / el, el
+
+        run(threads, 1.0)  # warm-up
+        runs = [run(threads, seconds) for _ in range(repeats)]
+        best = max(runs)
+        single = run(1, seconds)
+        return {"value": best[0], "unit": "accepted steps/s", "cores": int(threads), "kind": "port",
+                "single_core_value": single[0],
+                "sample": f"oracle/pn_oracle_c.c, {backend}; OpenMP, one trajectory per thread, {threads} trajectories of the same "
+                          f"batch for {seconds:.0f}s each: best of {repeats} runs after a warm-up "
+                          f"({', '.join(f'{r[0]:.0f}' for r in runs)} accepted steps/s; {best[1]:.0f} attempted steps/s); "
+                          f"{best[0] / threads:.1f} steps/s per core with all cores busy, {single[0]:.1f} on one core alone; "
+                          f"affinity mask {aff} cpus, cgroup quota {quota}, os.cpu_count() {os.cpu_count()}"}
     # fallback: NumPy oracle, single process
     import pn_oracle as po
     from helpers import oracle_problem
@@ -113,7 +149,7 @@ def cpu_baseline(seconds=15.0):
     accepted = 0
     t0 = time.perf_counter()
     ast = po.adaptive_init(po.initial_state(cfg, [c[0] for c in tcs], 0.0), DT0)
-    while time.perf_counter() - t0 < seconds:
+    while time.perf_counter() - t0 < 3 * seconds:
         ast = po.rejection_loop(cfg, acfg, prob, ast, np.inf)
         accepted += 1
     el = time.perf_counter() - t0
@@ -328,7 +364,7 @@ def main():
                 hbm["measured_frac"] = hbm["measured_GBps"] / HBM_PEAK_GBS
             out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "hbm": hbm,
                                "frac": achieved / FP64_PEAK_TFLOPS, "traffic": measured_traffic("dense_lq2_mfma_kernel", B),
-                               "traffic_source": "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
+                               "traffic_source": "profiles/r02_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
                                "kernel": "dense_lq2_mfma_kernel<16,true> + <16,false> (one LQ, two launches)",
                                "algorithmic_flops_per_launch": flops,
                                "phase_ms": {"begin": phase[0] / K, "lq_input": phase[1] / K, "lq": phase[2] / K,

@@ -9,8 +9,10 @@
  *   control_proportional_integral + adaptive            /root/reference/src/odecheckpts/ivpsolvers.py:52-53
  *   brusselator                                         /root/reference/src/odecheckpts/ivps.py:124-156
  */
+#include <dlfcn.h>
 #include <math.h>
 #include <stdlib.h>
+#include <stdio.h>
 #include <string.h>
 #include <time.h>
 #ifdef _OPENMP
@@ -18,6 +20,44 @@
 #endif
 
 #define MAXN 9
+
+/* Optional LAPACK / BLAS back end for the CPU baseline of bench.py: the Householder QR and the dense products go through the
+ * OpenBLAS that scipy ships (blocked dgeqrf, dgemm, dtrsm; one BLAS thread per OpenMP thread) instead of the plain loops below.
+ * pnoc_use_lapack(path) dlopens it; without it (or with path = NULL) the restatement runs on its own loops. Results agree to
+ * rounding (tests/test_oracle_c.py). */
+typedef void (*dgeqrf_t)(const int*, const int*, double*, const int*, double*, double*, const int*, int*);
+typedef void (*dgemm_t)(const char*, const char*, const int*, const int*, const int*, const double*, const double*, const int*,
+                        const double*, const int*, const double*, double*, const int*);
+typedef void (*dtrsm_t)(const char*, const char*, const char*, const char*, const int*, const int*, const double*, const double*,
+                        const int*, double*, const int*);
+static dgeqrf_t p_dgeqrf = NULL;
+static dgemm_t p_dgemm = NULL;
+static dtrsm_t p_dtrsm = NULL;
+
+int pnoc_use_lapack(const char* path) {
+  p_dgeqrf = NULL; p_dgemm = NULL; p_dtrsm = NULL;
+  if (!path) return 0;
+  void* h = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
+  if (!h) return -1;
+  const char* pre[2] = {"scipy_", ""};
+  for (int i = 0; i < 2 && !(p_dgeqrf && p_dgemm && p_dtrsm); ++i) {
+    char name[64];
+    snprintf(name, sizeof(name), "%sdgeqrf_", pre[i]); p_dgeqrf = (dgeqrf_t)dlsym(h, name);
+    snprintf(name, sizeof(name), "%sdgemm_", pre[i]); p_dgemm = (dgemm_t)dlsym(h, name);
+    snprintf(name, sizeof(name), "%sdtrsm_", pre[i]); p_dtrsm = (dtrsm_t)dlsym(h, name);
+    snprintf(name, sizeof(name), "%sopenblas_set_num_threads", pre[i]);
+    void (*setn)(int) = (void (*)(int))dlsym(h, name);
+    if (setn) setn(1);
+  }
+  if (!(p_dgeqrf && p_dgemm && p_dtrsm)) { p_dgeqrf = NULL; p_dgemm = NULL; p_dtrsm = NULL; return -2; }
+  return 1;
+}
+
+/* row-major C (r x c) = alpha op(A) op(B) + beta C through column-major dgemm (a row-major array IS the transposed column-major one) */
+static void gemm_rm(char ta, char tb, int r, int c, int k, double alpha, const double* A, int lda, const double* B, int ldb,
+                    double beta, double* C, int ldc) {
+  p_dgemm(&tb, &ta, &c, &r, &k, &alpha, B, &ldb, A, &lda, &beta, C, &ldc);
+}
 
 typedef struct {
   int nu, n, d, D;
@@ -65,6 +105,14 @@ static void precond(const iwp_t* w, double dt, double* p, double* pinv) {
  * n columns holds L with L L^T = A A^T (no sign normalisation); this is the transpose of the reference's
  * "R factor of a QR of A^T", laid out so that every inner loop runs over contiguous memory. */
 static void lq_inplace(double* A, int n, int m) {
+  if (p_dgeqrf) {
+    /* the row-major n x m array is the column-major m x n matrix A^T: its QR's R^T is the L of A, in the same memory cells */
+    int info = 0, lwork = 64 * n;
+    double* tau = (double*)malloc(sizeof(double) * (size_t)(n + lwork));
+    p_dgeqrf(&m, &n, A, &m, tau, tau + n, &lwork, &info);
+    free(tau);
+    return;
+  }
   for (int c = 0; c < n; ++c) {
     double* x = A + (size_t)c * m;
     double xx = 0.0;
@@ -169,18 +217,23 @@ double pnoc_dense_step(const iwp_t* w, int N, const double* mean, const double* 
   for (int r = 0; r < D; ++r) {
     const int i = r / d, q = r % d;
     double* row = stack + (size_t)r * 2 * D;
-    for (int c = 0; c < D; ++c) {
-      double acc = 0.0;
-      for (int k = i; k < n; ++k) acc += w->a[i][k] * pinv[k] * L[(size_t)(k * d + q) * D + c];
-      row[c] = acc;
-      const int ic = c / d, qc = c % d;
-      row[D + c] = (q == qc && ic <= i) ? sigma * w->qs[i][ic] : 0.0;
+    memset(row, 0, sizeof(double) * 2 * (size_t)D);
+    for (int k = i; k < n; ++k) {  /* (k outermost: unit-stride, vectorisable inner loop) */
+      const double ck = w->a[i][k] * pinv[k];
+      const double* lrow = L + (size_t)(k * d + q) * D;
+      for (int c = 0; c < D; ++c) row[c] += ck * lrow[c];
     }
+    for (int ic = 0; ic <= i; ++ic) row[D + ic * d + q] = sigma * w->qs[i][ic];
   }
   lq_inplace(stack, D, 2 * D);
   for (int r = 0; r < D; ++r)
     for (int c = 0; c < D; ++c) Lm[(size_t)r * D + c] = (c <= r) ? p[r / d] * stack[(size_t)r * 2 * D + c] : 0.0;
   /* correction: F = H L^-, S^(T/2) = qr_r(F^T), K = L^- F^T S^-1, m = m^- - K z, L = L^- - K F */
+  if (p_dgemm) {
+    memcpy(F, Lm + (size_t)d * D, sizeof(double) * (size_t)d * D);
+    gemm_rm('N', 'N', d, D, d, -1.0, J, d, Lm, D, 1.0, F, D);
+    gemm_rm('N', 'T', D, d, D, 1.0, Lm, D, F, D, 0.0, K, d);
+  } else {
   for (int a = 0; a < d; ++a)
     for (int c = 0; c < D; ++c) {
       double acc = Lm[(size_t)(d + a) * D + c];
@@ -194,8 +247,15 @@ double pnoc_dense_step(const iwp_t* w, int N, const double* mean, const double* 
       for (int c = 0; c <= r; ++c) acc += Lm[(size_t)r * D + c] * F[(size_t)a * D + c];
       K[(size_t)r * d + a] = acc;
     }
+  }
   memcpy(Ft, F, sizeof(double) * (size_t)d * D);
   lq_inplace(Ft, d, D);  /* C_s (d x d lower, leading dimension D): S = C_s C_s^T */
+  if (p_dtrsm) {
+    /* K^T (column-major d x D) <- C_s^-T C_s^-1 K^T; the row-major lower C_s is the column-major upper U = C_s^T */
+    const double one = 1.0;
+    p_dtrsm("L", "U", "T", "N", &d, &D, &one, Ft, &D, K, &d);
+    p_dtrsm("L", "U", "N", "N", &d, &D, &one, Ft, &D, K, &d);
+  } else
   for (int r = 0; r < D; ++r) {  /* K <- cross C_s^-T C_s^-1 */
     double* row = K + (size_t)r * d;
     for (int a = 0; a < d; ++a) {
@@ -213,11 +273,16 @@ double pnoc_dense_step(const iwp_t* w, int N, const double* mean, const double* 
     double acc = mext[r];
     for (int a = 0; a < d; ++a) acc -= K[(size_t)r * d + a] * z[a];
     mean_out[r] = acc;
+    if (p_dgemm) continue;
     for (int c = 0; c < D; ++c) {
       double v = Lm[(size_t)r * D + c];
       for (int a = 0; a < d; ++a) v -= K[(size_t)r * d + a] * F[(size_t)a * D + c];
       L_out[(size_t)r * D + c] = v;
     }
+  }
+  if (p_dgemm) {
+    memcpy(L_out, Lm, sizeof(double) * (size_t)D * D);
+    gemm_rm('N', 'N', D, D, d, -1.0, K, d, F, D, 1.0, L_out, D);
   }
   return sigma;
 }

@@ -53,22 +53,45 @@ def run(name, vf, u0s, t0, t1, *, model, corr, strategy, nu, atol, rtol, dt0, nu
     print(json.dumps(out), flush=True)
 
 
-def config5(B=64, t1=2.0, tol=1e-4):
+def _device_memory():
+    """(free, total) bytes of the current device through the HIP runtime (ctypes)."""
+    import ctypes as C
+
+    hip = C.CDLL("libamdhip64.so")
+    free, total = C.c_size_t(), C.c_size_t()
+    hip.hipMemGetInfo(C.byref(free), C.byref(total))
+    return free.value, total.value
+
+
+def config5(B=64, t1=2.0, tol=1e-4, num_save=5, strategies=("filter", "fixedpoint")):
     """C5: Brusselator N=128 (d=256), nu=3, dense EKF1 (D=1024), fixed-memory checkpoint smoothing; 64 trajectories per GPU
-    (512 over 8). Phase-shifted initial profiles as in bench.problem_batch."""
+    (512 over 8). Phase-shifted initial profiles as in bench.problem_batch. `c5full` = as specified: t in [0, 10], 200 save_at
+    points (experiments/4_brusselator/run.py:119), with the device memory in use printed before the line."""
     N = 128
     vf, u0, (t0, _), _ = ivps.brusselator(N)
     x = np.linspace(0.0, 1.0, N)
     ph = 2.0 * np.pi * np.arange(B) / B
     y0 = np.concatenate([1.0 + np.sin(2 * np.pi * x[None, :] + ph[:, None]), 3.0 * np.ones((B, N))], axis=1)
-    for strategy in ("filter", "fixedpoint"):
-        run(f"C5 brusselator N=128 dense EKF1 nu=3 {strategy}", vf, [y0], t0, t1, model="dense", corr="ts1", strategy=strategy,
-            nu=3, atol=tol, rtol=tol, dt0=0.01, num_save=5)
+    for strategy in strategies:
+        run(f"C5 brusselator N=128 dense EKF1 nu=3 {strategy}, t1={t1}, {num_save} save_at points, tol {tol}", vf, [y0], t0, t1,
+            model="dense", corr="ts1", strategy=strategy, nu=3, atol=tol, rtol=tol, dt0=0.01, num_save=num_save)
 
 
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "c5":
         config5()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "c5full":
+        D, K, B = 1024, 199, 64
+        plan = {"per_trajectory_MB": {"checkpoint transitions ck_G + ck_Lam (K x 2 x D^2 x 8 B)": 2 * K * D * D * 8 / 2**20,
+                                      "5 state slots (factor + running G, Lam): 15 x D^2 x 8 B": 15 * D * D * 8 / 2**20,
+                                      "LQ scratch M, R (2 x 2D x D x 8 B)": 4 * D * D * 8 / 2**20},
+                "batch": B}
+        plan["total_GB"] = B * sum(plan["per_trajectory_MB"].values()) / 1024
+        print(json.dumps({"config5_memory_plan": plan}), flush=True)
+        config5(B=B, t1=10.0, tol=1e-4, num_save=200, strategies=("fixedpoint",))
+        free, total = _device_memory()
+        print(json.dumps({"device_memory_after_solve_GB": {"free": free / 2**30, "total": total / 2**30}}), flush=True)
         return
     from scipy.integrate import solve_ivp
 

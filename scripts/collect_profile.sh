@@ -2,7 +2,7 @@
 # Run ON THE GPU BOX (through gpurun): kernel trace + three separate PMC passes of the default bench.
 # Output under gpurun_out/prof_<tag>/ ; summarise with scripts/summarize_profile.py and copy to profiles/.
 set -e
-TAG=${1:-r01}
+TAG=${1:-r02}
 OUT=gpurun_out/prof_$TAG
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf $OUT

@@ -5,6 +5,7 @@ import os
 
 import numpy as np
 import pn_oracle as po
+import pytest
 from helpers import brusselator_y0, oracle_problem, tcoeffs
 from probdiffeq_hip import vector_fields as V
 
@@ -26,8 +27,25 @@ def _p(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
-def test_c_step_matches_numpy_oracle():
+def _openblas_path():
+    import glob
+
+    import scipy
+
+    hits = glob.glob(os.path.join(os.path.dirname(scipy.__file__), "..", "scipy.libs", "libscipy_openblas*.so"))
+    return hits[0].encode() if hits else None
+
+
+@pytest.mark.parametrize("backend", ["loops", "lapack"])
+def test_c_step_matches_numpy_oracle(backend):
     lib = _lib()
+    lib.pnoc_use_lapack.argtypes = [C.c_char_p]
+    if backend == "lapack":
+        path = _openblas_path()
+        if path is None or lib.pnoc_use_lapack(path) != 1:
+            pytest.skip("no OpenBLAS with LAPACK found next to scipy")
+    else:
+        lib.pnoc_use_lapack(None)
     N, nu = 6, 3
     vf = V.brusselator(N)
     d, D = 2 * N, (nu + 1) * 2 * N
@@ -46,6 +64,7 @@ def test_c_step_matches_numpy_oracle():
         cov, cov_ref = Lo @ Lo.T, st.chol @ st.chol.T
         assert np.max(np.abs(cov - cov_ref)) < 1e-7 * np.max(np.abs(cov_ref))
         mean, L = mo, Lo
+    lib.pnoc_use_lapack(None)
 
 
 def test_c_bench_loop_runs_and_counts():
