@@ -25,7 +25,10 @@ import os
 import sys
 import time
 
-import numpy as np
+# the CPU baseline runs one trajectory per OpenMP thread with ONE BLAS thread each: keep OpenBLAS from spawning a pool per call
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for _p in (os.path.join(ROOT, "code-adaptive-prob-ode-solvers_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
