@@ -112,11 +112,13 @@ def _as_vf(vf):
     return vf
 
 
-# the dense filter stores a D x D covariance factor per save_at point when that fits this many bytes (else means only)
-CHECKPOINT_FACTOR_BYTES = 4 << 30
+# The dense filter stores a D x D covariance factor per save_at point (Posterior.checkpoint_factors) by default up to this state
+# dimension; beyond it on request (`checkpoint_factors=True`): the factor of an interpolated checkpoint costs a time update on
+# the generic kernels (69 ms for 1024 trajectories at D = 256) and B x K x D^2 x 8 bytes.
+CHECKPOINT_FACTORS_UP_TO_D = 64
 
 
-def _make_batch(vf, init: InitialCondition, solver: Solver, num_checkpoints, device=None):
+def _make_batch(vf, init: InitialCondition, solver: Solver, num_checkpoints, device=None, checkpoint_factors=None):
     vf = _as_vf(vf)
     st = solver.strategy
     B, n, d = init.tcoeffs.shape
@@ -140,8 +142,8 @@ def _make_batch(vf, init: InitialCondition, solver: Solver, num_checkpoints, dev
         batch=B, d=d, nu=st.prior.num_derivatives, ode_order=st.correction.ode_order, model=st.model,
         correction=st.correction.kind, strategy=kind, calibration=solver.calibration, vf_id=vf.vf_id,
         vf_params=prm, num_checkpoints=num_checkpoints, device=device,
-        checkpoint_factors=(st.model == "dense" and kind == "filter"
-                            and 8 * B * num_checkpoints * (n * d) ** 2 <= CHECKPOINT_FACTOR_BYTES),
+        checkpoint_factors=(st.model == "dense" and kind == "filter" and num_checkpoints > 0
+                            and (n * d <= CHECKPOINT_FACTORS_UP_TO_D if checkpoint_factors is None else bool(checkpoint_factors))),
     )
     return batch
 
@@ -242,13 +244,17 @@ def _python_save_at_loop(batch, loop, sa_b, K, nz):
 
 
 def solve_adaptive_save_at(vector_field, initial_condition: InitialCondition, save_at, adaptive_solver: AdaptiveSolver,
-                           dt0, *, device=None, python_controller=False, device_controller=False) -> Solution:
+                           dt0, *, device=None, python_controller=False, device_controller=False,
+                           checkpoint_factors=None) -> Solution:
     """Adaptive solve that stores the solution at `save_at` only (fixed memory, O(len(save_at))).
 
     save_at: (K+1,) shared or (B, K+1) per trajectory; save_at[..., 0] is the initial time. Steps are
     not clipped (unless control.clip): an accepted step that oversteps a checkpoint is interpolated.
     With strategy_fixedpoint, `Solution.u` holds the smoothed means (backward pass over the stored
     checkpoint transitions), as probdiffeq's solution object does.
+
+    `checkpoint_factors`: the dense filter also stores the covariance factor at every save_at point
+    (`solution.posterior.checkpoint_factors()`); default: yes up to (nu+1) d = 64, on request beyond.
 
     Controller placement: by default the PI controller and the accept/reject decisions run on the host (native
     loop inside the C-ABI; `python_controller=True` runs the same loop in NumPy). `device_controller=True`
@@ -265,7 +271,7 @@ def solve_adaptive_save_at(vector_field, initial_condition: InitialCondition, sa
     K = sa_b.shape[1] - 1
     if K < 1 or np.any(np.diff(sa_b, axis=1) <= 0):
         raise ValueError("save_at must be strictly increasing with at least two points")
-    batch = _make_batch(vector_field, init, solver, K, device)
+    batch = _make_batch(vector_field, init, solver, K, device, checkpoint_factors)
     batch.set_initial(init.tcoeffs, sa_b[:, 0], init.output_scale)
     batch.set_tolerances(adaptive_solver.atol, adaptive_solver.rtol)
     loop = _AdaptiveLoop(batch, adaptive_solver, sa_b[:, 0], dt0, vf=vector_field)

@@ -197,7 +197,7 @@ def test_checkpoint_covariance_factors_of_the_filter(hip_lib, case, monkeypatch)
     first = ivpsolve.solve_adaptive_save_every_step(vf, solver.initial_condition(tcs, 1.0), t0=save_at[0], t1=save_at[-1], dt0=dt0,
                                                     adaptive_solver=ivpsolve.adaptive(solver, atol=tol, rtol=tol))
     save_at = np.sort(np.append(save_at, first.t[3]))
-    sol = ivpsolve.solve_adaptive_save_at(vf, solver.initial_condition(tcs, 1.0), save_at=save_at, dt0=dt0,
+    sol = ivpsolve.solve_adaptive_save_at(vf, solver.initial_condition(tcs, 1.0), save_at=save_at, dt0=dt0, checkpoint_factors=True,
                                           adaptive_solver=ivpsolve.adaptive(solver, atol=tol, rtol=tol))
     cfg = po.SolverConfig(nu=nu, model=model, correction=corr, strategy="filter", calibration="dynamic")
     osol = po.solve_adaptive_save_at(cfg, po.AdaptiveConfig(tol, tol), oracle_problem(vf), po.initial_state(cfg, tcs, 0.0), save_at, dt0)
