@@ -346,12 +346,16 @@ __global__ __launch_bounds__(64 * kLqWaves) void dense_lq3_mfma_kernel(const Lq3
   do {                 \
   } while (0)
 #endif
-  double X[4 * DT];
-  bool have = false;
-  int mystrip = -1;
   const int npass = S->npass;
 #pragma unroll 1
   for (int P = 0; P < npass; ++P) {
+    // The strip a wavefront holds is NOT carried across this loop in registers: a strip kept for the next pass is parked in the
+    // (then free) LDS slot of the panel it will be and read back by the same wavefront at the top of the next pass. (With the
+    // 128 registers live across the back edge the register allocator routed them through scratch at every pass: 1.4 MB of
+    // HBM reads and as many writes per trajectory.)
+    double X[4 * DT];
+    bool have = false;
+    int mystrip = -1;
     const int c0 = kNB * NP * P;
     // Columns >= 2d of L^- are not touched by the measurement update (F = H L^- has 2d non-zero columns): the passes that
     // produce them write p_row * T straight into the destination slot of the state factor.
@@ -362,14 +366,18 @@ __global__ __launch_bounds__(64 * kLqWaves) void dense_lq3_mfma_kernel(const Lq3
       const int j0 = kNB * st, cp = c0 + kNB * k;
       double4_t tv;
       apply_panel_to_strip<DT, LDV>(Xs, Vx + k * kNB * LDV, TfS + k * kNB * kNB, sclS + k * kNB, t0_tile(j0, cp), tv, r, g);
-      if (direct) {
-        const double osc = pS[(j0 + r) / d];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) Ldst[tiled_index<DT>(j0 + r, cp + g + 4 * q)] = osc * tv[q];
+      tv = transpose_groups(tv);  // lane (r, g): columns cp + 4 g .. cp + 4 g + 3 of row j0 + r
+      const double osc = direct ? pS[(j0 + r) / d] : 1.0;
+      double2 lo2, hi2;
+      lo2.x = osc * tv[0]; lo2.y = osc * tv[1]; hi2.x = osc * tv[2]; hi2.y = osc * tv[3];
+      if (direct) {  // strip order of the state factor: two pairs per lane, 16 lanes of a pair contiguous
+        double* base = Ldst + tiled_index<DT>(j0 + r, cp + 4 * g);
+        *reinterpret_cast<double2*>(base) = lo2;
+        *reinterpret_cast<double2*>(base + 128) = hi2;  // next pair: + 64 lanes x 2 doubles
       } else {
-        double* Trow = T + size_t(j0 + r) * D + cp;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) Trow[g + 4 * q] = tv[q];
+        double* Trow = T + size_t(j0 + r) * D + cp + 4 * g;
+        *reinterpret_cast<double2*>(Trow) = lo2;
+        *reinterpret_cast<double2*>(Trow + 2) = hi2;
       }
     };
     int mypanel = -1;
@@ -382,10 +390,16 @@ __global__ __launch_bounds__(64 * kLqWaves) void dense_lq3_mfma_kernel(const Lq3
     for (int task = 0; task < ntasks; ++task) {
       if (task == 0) {
         if (mypanel >= 0) {
+          mystrip = NP * P + mypanel;
+          have = true;
           if (P == 0) {
-            mystrip = mypanel;
             load_strip(mystrip, X, true);
-            have = true;
+          } else {
+            const double* Vp = Vx + mypanel * kNB * LDV;  // parked here by this wavefront at the end of the previous pass
+#pragma unroll
+            for (int T4 = 0; T4 < DT / 4; ++T4)
+#pragma unroll
+              for (int e = 0; e < 16; ++e) X[16 * T4 + e] = Vp[r * LDV + 64 * T4 + 16 * g + e];
           }
         } else {
           const int s = S->shadow[P][wv];
@@ -464,10 +478,17 @@ __global__ __launch_bounds__(64 * kLqWaves) void dense_lq3_mfma_kernel(const Lq3
           have = false;
         }
         LQ_STAMP(6);
+        if (have) break;  // a strip kept for the next pass: its wavefront takes no further task in this one
       }
-      // (a carried strip stays: its wavefront is a panel wavefront of the next pass and takes no further task in this one)
     }
-    __syncthreads();  // every wavefront is done with this pass's reflectors before the next pass overwrites them
+    __syncthreads();  // every wavefront is done with this pass's reflectors before their LDS slots are reused
+    if (have) {
+      double* Vp = Vx + (mystrip - NP * (P + 1)) * kNB * LDV;  // the slot of the panel this strip is in the next pass
+#pragma unroll
+      for (int T4 = 0; T4 < DT / 4; ++T4)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) Vp[r * LDV + 64 * T4 + 16 * g + e] = X[16 * T4 + e];
+    }
     LQ_STAMP(7);
   }
 #ifdef PNODE_TIMING_BUILD

@@ -64,6 +64,30 @@ __device__ __forceinline__ size_t tiled_index(int row, int col) {  // element in
   return ((size_t(s) * (2 * DT) + 8 * T + (e >> 1)) * 64 + r + 16 * g) * 2 + (e & 1);
 }
 
+// 4 x 4 transpose of a C/D fragment among the four 16-lane rows of the wavefront: in, lane (r, g) holds columns g + 4 q of
+// row r (q = 0..3); out, columns 4 g + q -- four CONSECUTIVE columns per lane, so that a tile of T leaves the wavefront in
+// whole 128-byte rows instead of scattered 8-byte pieces. Two rounds of v_permlane32_swap / v_permlane16_swap (gfx950).
+__device__ __forceinline__ void swap32(double& a, double& b) {
+  auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+  auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+  a = __hiloint2double(hi[0], lo[0]);
+  b = __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ void swap16(double& a, double& b) {
+  auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
+  auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
+  a = __hiloint2double(hi[0], lo[0]);
+  b = __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ double4_t transpose_groups(double4_t t) {
+  double a0 = t[0], a1 = t[1], a2 = t[2], a3 = t[3];
+  swap32(a0, a2);  // rows {2, 3} of register 0 <-> rows {0, 1} of register 2
+  swap32(a1, a3);
+  swap16(a0, a1);  // rows {1, 3} of register 0 <-> rows {0, 2} of register 1
+  swap16(a2, a3);
+  return double4_t{a0, a1, a2, a3};
+}
+
 // One panel's reflectors applied to a register strip X (HBM layout). Returns T[J][P] = T0 - W in tvals (C/D fragment:
 // lane (r, g) holds columns g + 4 q of row r).
 template <int DT, int LDV>
