@@ -1236,7 +1236,7 @@ int pnode_set_generic_path(pnode_batch* h, int32_t enabled) {
   h->dn.force_generic = enabled == 1 || h->dn.fixedpoint;  // the register-resident MFMA kernels have no extra-row LQ
   h->dn.user_generic = enabled == 1;
   h->dn.force_large = enabled == 2;
-  h->dn.lq_one_launch = enabled == 3;
+  h->dn.lq_one_launch = enabled == 3 ? 1 : (enabled == 4 ? 2 : 0);
   return PNODE_OK;
 }
 

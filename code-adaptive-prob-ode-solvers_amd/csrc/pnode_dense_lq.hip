@@ -18,7 +18,7 @@
 // time update by QR of the stacked factor); arithmetic restated in oracle/pn_oracle.py (predict_sqrt).
 #include <cstring>
 
-#include "pnode_mfma_common.hpp"
+#include "pnode_lq_sweep.hpp"
 
 namespace pnode {
 
@@ -68,146 +68,6 @@ bool lq_build_schedule(int DT, int NP, LqSchedule* S) {
     S->nrounds[P] = int8_t(rd);
   }
   return true;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Register-resident panel factorisation in the strip layout.
-// ---------------------------------------------------------------------------------------------------------------------
-template <int C>
-__device__ __forceinline__ double bcast16(double v) {  // lane C of every 16-lane DPP row -> all lanes of that row
-  return __builtin_amdgcn_update_dpp(v, v, 0x150 + C, 0xf, 0xf, false);
-}
-
-// acc_i += x_e(lane C of the row) * x_e(this lane): the dot product of every row with row C, partial over this lane's columns.
-// (s_nop 1: a VGPR written by a VALU instruction needs two wait states before a DPP read; nothing pads inside asm.)
-template <int C>
-__device__ __forceinline__ void dot16(double& a0, double& a1, double& a2, double& a3, double x0, double x1, double x2, double x3, double x4, double x5, double x6, double x7, double x8, double x9, double x10, double x11, double x12, double x13, double x14, double x15) {
-  asm volatile(
-      "s_nop 1\n\t"
-      "v_fmac_f64_dpp %0, %4, %4 row_newbcast:%20 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %1, %5, %5 row_newbcast:%20 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %2, %6, %6 row_newbcast:%20 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %3, %7, %7 row_newbcast:%20 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %0, %8, %8 row_newbcast:%20 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %1, %9, %9 row_newbcast:%20 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %2, %10, %10 row_newbcast:%20 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %3, %11, %11 row_newbcast:%20 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %0, %12, %12 row_newbcast:%20 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %1, %13, %13 row_newbcast:%20 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %2, %14, %14 row_newbcast:%20 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %3, %15, %15 row_newbcast:%20 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %0, %16, %16 row_newbcast:%20 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %1, %17, %17 row_newbcast:%20 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %2, %18, %18 row_newbcast:%20 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %3, %19, %19 row_newbcast:%20 row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 0"
-      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)
-      : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(x4), "v"(x5), "v"(x6), "v"(x7), "v"(x8), "v"(x9), "v"(x10), "v"(x11), "v"(x12), "v"(x13), "v"(x14), "v"(x15), "i"(C));
-}
-// x_e += x_e(lane C of the row) * nws  (nws = 0 on the lanes whose row is not updated, lane C included)
-template <int C>
-__device__ __forceinline__ void upd16(double& x0, double& x1, double& x2, double& x3, double& x4, double& x5, double& x6, double& x7, double& x8, double& x9, double& x10, double& x11, double& x12, double& x13, double& x14, double& x15, double nws) {
-  asm volatile(
-      "s_nop 1\n\t"
-      "v_fmac_f64_dpp %0, %0, %16 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %1, %1, %16 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %2, %2, %16 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %3, %3, %16 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %4, %4, %16 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %5, %5, %16 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %6, %6, %16 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %7, %7, %16 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %8, %8, %16 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %9, %9, %16 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %10, %10, %16 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %11, %11, %16 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %12, %12, %16 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %13, %13, %16 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %14, %14, %16 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %15, %15, %16 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 0"
-      : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7), "+v"(x8), "+v"(x9), "+v"(x10), "+v"(x11), "+v"(x12), "+v"(x13), "+v"(x14), "+v"(x15)
-      : "v"(nws), "i"(C));
-}
-
-// Sum of a value over the four 16-lane DPP rows of the wavefront (the four column groups of the strip layout); every lane
-// receives the total, formed in the same order. v_permlane16_swap exchanges rows 1 <-> 0 and 3 <-> 2 between its two operands,
-// v_permlane32_swap the upper half of one with the lower half of the other (gfx950).
-__device__ __forceinline__ double sum_over_groups(double v) {
-  unsigned lo = __double2loint(v), hi = __double2hiint(v);
-  auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-  auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-  v = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
-  lo = __double2loint(v);
-  hi = __double2hiint(v);
-  auto c = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-  auto e = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-  return __hiloint2double(e[0], c[0]) + __hiloint2double(e[1], c[1]);
-}
-
-// acc += tfrow[M] * u(lane M of the row), M = 0 .. C-1: one DPP-operand FMA per term
-template <int M, int C>
-__device__ __forceinline__ void tf_accumulate(double& acc, double u, const double (&tfrow)[kNB]) {
-  if constexpr (M < C) {
-    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(u), "v"(tfrow[M]), "i"(M));
-    tf_accumulate<M + 1, C>(acc, u, tfrow);
-  }
-}
-
-// Pivot C of the sweep. On entry rows 0 .. C are final (row C received its last update at pivot C - 1).
-//   v_C = [e_C ; scl_C x_C]  (x_C stays unscaled in the registers),  H_C = I - tau_C v_C^T v_C.
-// tpp_row[C] <- T[row r][column C of the panel]  (beta on the diagonal, -w below, 0 above), staged in LDS
-// tfrow[C] <- Tf[r][C] of the compact-WY factor, H_0 ... H_C = I - V^T Tf V  (forward recurrence, dlarft)
-template <int C, int DT>
-__device__ __forceinline__ void pivot_step(double (&X)[4 * DT], double (&tfrow)[kNB], double* __restrict__ tpp_row, double& myscl,
-                                           double alpha, int r_) {
-  int r = r_;
-  asm volatile("" : "+v"(r));  // opaque: the per-pivot lane predicates are formed here, not hoisted out of the pass loop
-  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-#pragma unroll
-  for (int e = 0; e < 4 * DT; e += 16)
-    dot16<C>(a0, a1, a2, a3, X[e], X[e + 1], X[e + 2], X[e + 3], X[e + 4], X[e + 5], X[e + 6], X[e + 7], X[e + 8], X[e + 9],
-             X[e + 10], X[e + 11], X[e + 12], X[e + 13], X[e + 14], X[e + 15]);
-  const double part = (a0 + a1) + (a2 + a3);
-  const double dotv = sum_over_groups(part);  // every lane of row r holds x_r . x_C
-  const double xx = bcast16<C>(dotv);  // |x_C|^2
-  double tauc = 0.0, scale = 0.0, beta = alpha;
-  {
-    const double nrm2 = fma(alpha, alpha, xx);
-    const double rs = fast_rsqrt(nrm2);
-    const double sgn = copysign(1.0, alpha);
-    const double t1 = fma(fabs(alpha), rs, 1.0);
-    const bool refl = xx != 0.0;  // (NaN != 0: a NaN row propagates, like the reference's QR)
-    beta = refl ? -sgn * nrm2 * rs : alpha;
-    tauc = refl ? t1 : 0.0;
-    scale = refl ? sgn * rs * fast_rcp(t1) : 0.0;
-  }
-  const double w = tauc * scale * dotv;  // (the rows of one panel have no T0 entry in each other's columns)
-  const double nws = (r > C) ? -(w * scale) : 0.0;
-  tpp_row[C] = (r > C) ? -w : ((r == C) ? beta : 0.0);  // (the four lanes of a row store the same value)
-  {
-    const double u = (r < C) ? myscl * scale * dotv : 0.0;  // v_r . v_C for the finished reflectors r < C
-    double acc = 0.0;
-    tf_accumulate<0, C>(acc, u, tfrow);
-    tfrow[C] = (r < C) ? -tauc * acc : ((r == C) ? tauc : 0.0);
-  }
-  myscl = (r == C) ? scale : myscl;
-  // pin the recurrence inside its pivot: without this the scheduler sinks all 120 broadcasts below the last asm block of the
-  // sweep (they only feed the publication), spilling their operands on the way
-  asm volatile("" : "+v"(tfrow[C]), "+v"(myscl));
-#pragma unroll
-  for (int e = 0; e < 4 * DT; e += 16)
-    upd16<C>(X[e], X[e + 1], X[e + 2], X[e + 3], X[e + 4], X[e + 5], X[e + 6], X[e + 7], X[e + 8], X[e + 9], X[e + 10], X[e + 11],
-             X[e + 12], X[e + 13], X[e + 14], X[e + 15], nws);
-}
-
-template <int C, int DT>
-__device__ __forceinline__ void pivot_sweep(double (&X)[4 * DT], double (&tfrow)[kNB], double* __restrict__ tpp_row, double& myscl,
-                                            double alpha, int r) {
-  if constexpr (C < kNB) {
-    pivot_step<C, DT>(X, tfrow, tpp_row, myscl, alpha, r);
-    pivot_sweep<C + 1, DT>(X, tfrow, tpp_row, myscl, alpha, r);
-  }
 }
 
 struct Lq3Args {  // ONE by-value kernel argument: the schedule is read through the kernarg segment pointer (scalar loads with

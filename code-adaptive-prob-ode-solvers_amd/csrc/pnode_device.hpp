@@ -42,8 +42,8 @@ struct DenseView {
   int B, d, k, n, D, K;
   int ts1, dynamic, vf_id, P, prm_per_traj;
   int force_generic;  // 1: never take the MFMA fast path (A/B testing)
-  int lq_one_launch;  // 1: MFMA fast path with the one-launch, 64-row-pass LQ of pnode_dense_lq.hip (less HBM traffic, faster up to
-                      // one trajectory per CU) instead of the two-launch, 32-row-pass LQ (faster when several trajectories share a CU)
+  int lq_one_launch;  // LQ of the MFMA fast path. 0: two launches, 32-row passes (pnode_dense_mfma.hip); 1: one launch, 64-row
+                      // passes, one wavefront per panel (pnode_dense_lq.hip); 2: one launch, column-split groups (pnode_dense_lqc.hip)
   double* mean;   // [3][B][n][d]
   double* U;      // [3][B][D][D]   Sigma = U^T U (row-major)
   double* sigma;  // [3][B]
@@ -105,6 +105,8 @@ struct LqSchedule {
 bool lq_build_schedule(int DT, int NP, LqSchedule* S);
 bool dense_lq3_supported(const DenseView& v);
 void dense_launch_lq3(const DenseView& v, const StepArg* args, const IwpConst* K, hipStream_t s);
+bool dense_lqc_supported(const DenseView& v);
+void dense_launch_lqc(const DenseView& v, const StepArg* args, const IwpConst* K, hipStream_t s);
 
 // Optional per-phase timing of one dense step: events[0..4] bracket begin | lq_input | lq | correct.
 struct PhaseEvents {

@@ -247,7 +247,10 @@ def test_dense_inactive_and_rejected_trajectories_untouched(hip_lib, case):
     batch.close()
 
 
-@pytest.mark.parametrize("lq", ["two_launch", "one_launch"])
+LQ_PATHS = {"two_launch": 0, "one_launch": 3, "column_split": 4}  # pnode_set_generic_path values of the MFMA path's LQ kernels
+
+
+@pytest.mark.parametrize("lq", list(LQ_PATHS))
 @pytest.mark.parametrize("N,nu", [(16, 3), (32, 3), (16, 5), (32, 4)])
 def test_dense_mfma_path_matches_oracle_and_generic(hip_lib, N, nu, lq):
     """The MFMA-tiled LQ / measurement-update kernels (d % 16 == 0) against the oracle and against the
@@ -260,8 +263,8 @@ def test_dense_mfma_path_matches_oracle_and_generic(hip_lib, N, nu, lq):
     tc = tcoeffs(vf, [y0], nu)
     tc_arr = np.stack(tc, axis=1)
     fast = _dense_batch(vf, nu, "ts1", B)
-    if lq == "one_launch":
-        fast.set_generic_path(3)
+    if LQ_PATHS[lq]:
+        fast.set_generic_path(LQ_PATHS[lq])
     slow = _dense_batch(vf, nu, "ts1", B)
     slow.set_generic_path(True)
     for bt in (fast, slow):
