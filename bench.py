@@ -169,8 +169,9 @@ def main():
                     help="trajectories in the global batch (--scaling strong) or per GPU (--scaling weak)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="strong: ONE batch of --batch trajectories sharded over the GPUs (BASELINE config 4); weak: --batch per GPU")
-    ap.add_argument("--lq", default="auto", choices=["auto", "two-launch", "one-launch"],
-                    help="time update of the MFMA path; auto: one-launch LQ up to 256 trajectories on the GPU, two-launch beyond")
+    ap.add_argument("--lq", default="one-launch", choices=["one-launch", "two-launch"],
+                    help="time update of the MFMA path: the library's default (one launch, overlapping 64-row passes) or the "
+                         "two-launch kernels with 32-row passes (A/B comparison)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--controller", default="device", choices=["device", "host"],
                     help="device: accept/reject + PI law in a controller kernel between the attempts, the timed steps are enqueued "
@@ -226,11 +227,10 @@ def main():
     asolver = ivpsolve.adaptive(solver, atol=TOL, rtol=TOL)
     init = solver.initial_condition(tcs, 1.0)
     batch = ivpsolve._make_batch(vf, init, solver, 1, device=local)
-    # time update of the MFMA path: the two-launch LQ (32-row passes, two workgroups per CU) is the faster one when several
-    # trajectories share a CU; with at most one trajectory per CU -- the shards of the strong-scaling runs -- the one-launch LQ
-    # (64-row passes, panels factorised in registers, half the HBM traffic) is: 0.41 against 0.51 ms at 128 trajectories.
-    one_launch_lq = dense and ((B <= 256 and args.lq == "auto") or args.lq == "one-launch")
-    if dense and one_launch_lq:
+    # time update of the MFMA path: the library default is the one-launch LQ (pnode_dense_lq4.hip); the kernel choice never
+    # depends on the batch size (a shard of a batch must give the bits of the unsharded solve)
+    one_launch_lq = dense and args.lq == "one-launch"
+    if dense and not one_launch_lq:
         batch.set_generic_path(3)
     batch.set_initial(init.tcoeffs, np.zeros(B), init.output_scale)
     batch.set_tolerances(TOL, TOL)
@@ -351,7 +351,7 @@ def main():
                                    + (f", {B} trajectories on rank 0" if world > 1 else ""),
                        "batch_per_gpu": B, "global_batch": total, "parallelism": f"shard{world}",
                        "gather": gather_how if world > 1 else None,
-                       "lq_kernel": ("one-launch (64-row passes)" if one_launch_lq else "two-launch (32-row passes)") if dense else None,
+                       "lq_kernel": ("one-launch (overlapping 64-row passes)" if one_launch_lq else "two-launch (32-row passes)") if dense else None,
                        "controller": "device-resident (controller kernel between the attempts, one host synchronisation for the "
                                      "K timed steps)" if device_ctl else "host (one round trip per step)",
                        "attempted_steps_per_s": total * K / elapsed,
@@ -375,9 +375,9 @@ def main():
                 hbm["measured_GBps"] = meas_bytes / (step_ms * 1e-3) / 1e9
                 hbm["measured_frac"] = hbm["measured_GBps"] / HBM_PEAK_GBS
             out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "hbm": hbm,
-                               "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None if one_launch_lq else measured_traffic("dense_lq2_mfma_kernel", B),
+                               "frac": achieved / FP64_PEAK_TFLOPS, "traffic": measured_traffic("dense_lq4_mfma_kernel" if one_launch_lq else "dense_lq2_mfma_kernel", B),
                                "traffic_source": "profiles/r02_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
-                               "kernel": "dense_lq3_mfma_kernel<16,4,4> (one launch)" if one_launch_lq else
+                               "kernel": "dense_lq4_mfma_kernel<16,4> (one launch)" if one_launch_lq else
                                          "dense_lq2_mfma_kernel<16,true> + <16,false> (one LQ, two launches)",
                                "algorithmic_flops_per_launch": flops,
                                "phase_ms": {"begin": phase[0] / K, "lq_input": phase[1] / K, "lq": phase[2] / K,

@@ -1236,7 +1236,7 @@ int pnode_set_generic_path(pnode_batch* h, int32_t enabled) {
   h->dn.force_generic = enabled == 1 || h->dn.fixedpoint;  // the register-resident MFMA kernels have no extra-row LQ
   h->dn.user_generic = enabled == 1;
   h->dn.force_large = enabled == 2;
-  h->dn.lq_one_launch = enabled == 3 ? 1 : (enabled == 4 ? 2 : 0);
+  h->dn.lq_two_launch = enabled == 3;
   return PNODE_OK;
 }
 
@@ -1260,19 +1260,12 @@ void* pnode_stream(pnode_batch* h) { return h ? (void*)h->stream : nullptr; }
 // Diagnostic build only (make timing -> libpnode_hip_timing.so): 64-bit words of trajectory b's S scratch (in-kernel cycle stamps).
 int pnode_debug_read_scratch(pnode_batch* h, int32_t b, int32_t offset_words, int32_t count, uint64_t* out) {
   if (!h || !out || !h->dense) return fail(PNODE_EINVAL, "bad argument");
-  const size_t D = h->D, d = h->cfg.d;
+  const size_t d = h->cfg.d;
   HIP_TRY(hipMemcpy(out, reinterpret_cast<uint64_t*>(h->dn.S + size_t(b) * d * d) + offset_words, size_t(count) * 8,
                     hipMemcpyDeviceToHost));
   return PNODE_OK;
 }
 #endif
 
-int pnode_lq_schedule(int32_t num_strips, int32_t panels_per_pass, int8_t* out, int32_t capacity) {
-  if (!out || capacity < int32_t(sizeof(LqSchedule))) return fail(PNODE_EINVAL, "buffer too small for the schedule table");
-  LqSchedule S;
-  if (!lq_build_schedule(num_strips, panels_per_pass, &S)) return fail(PNODE_EINVAL, "no schedule for this shape");
-  std::memcpy(out, &S, sizeof(S));
-  return int(sizeof(S));
-}
 
 }  // extern "C"

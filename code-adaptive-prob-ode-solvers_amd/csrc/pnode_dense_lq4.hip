@@ -1,0 +1,337 @@
+// Time update of the dense EKF1 fast path, ONE launch, overlapping passes: blocked row-Householder LQ of the D x 2D stack
+// [T0 | Mt] with 64-row passes, one workgroup of 8 wavefronts per trajectory, two groups of four wavefronts (A = 0..3,
+// B = 4..7) that ALTERNATE as the panel group of the passes.
+//
+//   * A wavefront holds one 16-row strip of Mt (full width) in registers, a group one 64-row block. In pass P the panel group
+//     holds block P: wavefront j applies the panels 0 .. j-1 of the pass as they are published, factorises its own strip in
+//     registers (pnode_lq_sweep.hpp: DPP-operand FMAs, no LDS, no barrier) and publishes it as panel j (V = [e ; scl x], the
+//     compact-WY factor and the scales, in LDS slot j). The other group holds block P + 1 and applies every panel the moment it
+//     is published, so that ITS chain (pass P + 1) starts as soon as panel 3 is applied -- beside the remaining updates of pass P,
+//     which the wavefronts of the former panel group stream as they come free (strip j of the blocks P + 3 .. back to HBM, strip j
+//     of block P + 2 last: it is kept and is that wavefront's panel in pass P + 2).
+//   * The serial chain of the 4 D/64 x 4 sweeps, which bounds the kernel, therefore never waits for trailing updates, and at
+//     D = 256 only one 64-row block makes one round trip through HBM (none at D <= 192).
+//   * No workgroup barrier after the prologue. pubS[k] = P + 1: panel k of pass P is in LDS; freeS[k] counts the wavefronts
+//     that are done with slot k (8 per pass: the writer of the next pass waits for 8 (P + 1)); storedS[j]: strip j of the
+//     blocks parked in HBM by pass P. Every wait is a bounded spin (a wavefront that runs into the limit raises the abort word,
+//     all waits then fall through and the outputs of the trajectory are NaN).
+//   * (A column-split variant -- four wavefronts sweeping a quarter of the columns each -- was measured and dropped: an LDS
+//     round trip costs 300-400 cycles under load, so the per-pivot exchange of the partial dot products, 850 cycles, outweighs
+//     the four times shorter DPP sweep.)
+//
+// Reference anchors: strategy_filter (/root/reference/experiments/1_van_der_pol/vdp.py:65) as probdiffeq runs it (sqrt
+// time update by QR of the stacked factor); arithmetic restated in oracle/pn_oracle.py (predict_sqrt).
+#include "pnode_lq_sweep.hpp"
+
+namespace pnode {
+namespace lq4 {
+
+constexpr int kSpinLimit = 1 << 21;
+// The words the wavefronts talk through are accessed through pointers that CARRY the LDS address space: a volatile access
+// through a generic pointer is not rewritten by the address-space inference and becomes a flat_load / flat_store.
+using lds_int = __attribute__((address_space(3))) int;
+
+// Cycle stamps of the diagnostic build (make timing); empty otherwise.
+struct Stamps {
+#ifdef PNODE_TIMING_BUILD
+  unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long prev = 0;
+  __device__ __forceinline__ void start() { prev = __builtin_amdgcn_s_memtime(); }
+  __device__ __forceinline__ void mark(int slot) {
+    const unsigned long long now = __builtin_amdgcn_s_memtime();
+    acc[slot] += now - prev;
+    prev = now;
+  }
+#else
+  __device__ __forceinline__ void start() {}
+  __device__ __forceinline__ void mark(int) {}
+#endif
+};
+
+}  // namespace lq4
+
+template <int DT, int DD>
+__global__ __launch_bounds__(512) void dense_lq4_mfma_kernel(const DenseView v, const StepArg* __restrict__ args,
+                                                              const IwpConst* __restrict__ Kc) {
+  using namespace lq4;
+  static_assert(DT % 4 == 0, "whole 64-row blocks");
+  static_assert((2 * 16 * DD) % 64 == 0, "a pass is all below or all beyond column 2d");
+  constexpr int D = 16 * DT, d = 16 * DD, NBLK = DT / 4;
+  constexpr int LDV = D + 1;  // odd: the A-operand reads of the G phase (16 rows x 4 column groups) spread over the banks
+  __shared__ double Vx[4 * kNB * LDV];
+  __shared__ double TfS[4 * kNB * kNB];
+  __shared__ double sclS[4 * kNB];
+  __shared__ double TppS[4 * kNB * kNB];  // diagonal blocks of T, staged by the panel wavefront for a coalesced write
+  __shared__ double coef[kMaxN * kMaxN];
+  __shared__ double pS[kMaxN];
+  __shared__ int pubS[4], freeS[4], storedS[4];
+  __shared__ int abortS;
+
+  const int b = blockIdx.x;
+  const StepArg sarg = args[b];
+  if (!sarg.active) return;
+  const IwpConst& K = *Kc;
+  const int nn = v.n;
+  const double sigma = v.sig_new[b];
+  double* __restrict__ Mt = v.M + size_t(b) * D * D;
+  double* __restrict__ T = v.R + size_t(b) * D * D;
+  const double* __restrict__ Lsrc = v.U + (size_t(sarg.src) * v.B + b) * D * D;
+  double* __restrict__ Ldst = v.U + (size_t(sarg.dst) * v.B + b) * D * D;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int gi = wv >> 2, j = wv & 3;
+  if (tid == 0) {
+    // Mt = (Abar P^-1 (x) I) L is formed while the strips are read: coef[i][k] = Abar[i][k] / p_k
+    double pl[kMaxN], pil[kMaxN];
+    precond_rt(nn, sarg.dt, K, pl, pil);
+    for (int i = 0; i < nn; ++i)
+      for (int k = 0; k < nn; ++k) coef[i * kMaxN + k] = (k >= i) ? K.a[i][k] * pil[k] : 0.0;
+    for (int i = 0; i < kMaxN; ++i) pS[i] = (i < nn) ? pl[i] : 0.0;
+    for (int k = 0; k < 4; ++k) pubS[k] = freeS[k] = storedS[k] = 0;
+    abortS = 0;
+  }
+  __syncthreads();  // the only workgroup barrier
+
+  volatile lds_int* abort_word = (volatile lds_int*)&abortS;
+  auto spin_ge = [&](int* f_, int target) {
+    volatile lds_int* f = (volatile lds_int*)f_;
+    int n = 0;
+    while (__builtin_amdgcn_readfirstlane(*f) < target) {
+      __builtin_amdgcn_s_sleep(2);
+      if ((++n & 255) == 0 && (n > kSpinLimit || __builtin_amdgcn_readfirstlane(*abort_word))) {
+        *abort_word = 1;
+        break;
+      }
+    }
+    asm volatile("" ::: "memory");
+  };
+  auto lds_done = [] { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+  auto bump = [&](int* f) {  // my LDS reads / writes issued so far have completed before the counter moves
+    lds_done();
+    if (lane == 0) __hip_atomic_fetch_add((lds_int*)f, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  // (lane coordinates made opaque per call site: otherwise every LDS / HBM address of every call is hoisted out of the pass
+  // loop as a loop invariant and the hoisted addresses alone overflow the register file)
+  auto opaque = [](int x) {
+    asm volatile("" : "+v"(x));
+    return x;
+  };
+  Stamps st;
+
+  auto t0_tile = [&](int row0, int colp, int r, int g) {
+    // T0[row0 + r][colp + g + 4q] = sigma chol(Qbar)[ib][jb] where the intra-block indices agree
+    double4_t t;
+    const int ib = row0 / d, jb = colp / d;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      t[q] = (((row0 + r) % d) == ((colp + g + 4 * q) % d) && jb <= ib) ? sigma * K.qsT[jb][ib] : 0.0;
+    return t;
+  };
+
+  double X[4 * DT];  // my strip: X[16 T + e] = M[row0 + r][64 T + 16 g + e]
+
+  auto load_strip = [&](int st_, bool from_state) {
+    const int ln = opaque(tid & 63);
+    const int j0 = kNB * st_;
+    if (from_state) {
+      // Mt rows of derivative block ib: sum_{k >= ib} coef[ib][k] L[k d + q]: one round trip to memory per 64-column group and
+      // k, eight 16-byte loads per lane in flight (sixteen, two terms per round trip, measured slower); k runs downwards so that wavefronts which start together ask for the same
+      // rows of L at the same time
+      const int ib = j0 / d;
+#pragma unroll
+      for (int e = 0; e < 4 * DT; ++e) X[e] = 0.0;
+#pragma unroll
+      for (int T4 = 0; T4 < DT / 4; ++T4) {
+#pragma unroll 1
+        for (int k = nn - 1; k >= ib; --k) {
+          const double ck = coef[ib * kMaxN + k];
+          const double2* __restrict__ lrow = reinterpret_cast<const double2*>(Lsrc) + (size_t((k * d + j0 % d) / kNB) * (2 * DT) + 8 * T4) * 64 + ln;
+          double2 tmp[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) tmp[e] = lrow[e * 64];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            X[16 * T4 + 2 * e] = fma(ck, tmp[e].x, X[16 * T4 + 2 * e]);
+            X[16 * T4 + 2 * e + 1] = fma(ck, tmp[e].y, X[16 * T4 + 2 * e + 1]);
+          }
+        }
+      }
+    } else {
+      const double2* __restrict__ src = reinterpret_cast<const double2*>(Mt) + size_t(st_) * (2 * DT) * 64 + ln;
+#pragma unroll
+      for (int pp = 0; pp < 2 * DT; ++pp) {
+        const double2 t2 = src[pp * 64];
+        X[2 * pp] = t2.x;
+        X[2 * pp + 1] = t2.y;
+      }
+    }
+  };
+  auto store_strip = [&](int st_) {
+    const int ln = opaque(tid & 63);
+    double2* __restrict__ dst = reinterpret_cast<double2*>(Mt) + size_t(st_) * (2 * DT) * 64 + ln;
+#pragma unroll
+    for (int pp = 0; pp < 2 * DT; ++pp) dst[pp * 64] = double2{X[2 * pp], X[2 * pp + 1]};
+  };
+  // Columns >= 2d of L^- are not touched by the measurement update (F = H L^- has 2d non-zero columns): the passes that
+  // produce them write p_row * T straight into the destination slot of the state factor.
+  auto is_direct = [&](int pass) { return 64 * pass >= 2 * d; };
+  // panel k of pass `pass` applied to my strip (global strip index st_), once it is published. (Raising the issue priority of
+  // the applications the chain is waiting for changed nothing measurable.)
+  auto apply_panel = [&](int pass, int k, int st_) {
+    spin_ge(&pubS[k], pass + 1);
+    st.mark(1);
+    const int r = opaque(lane & 15), g = opaque(lane >> 4);
+    const int j0 = kNB * st_, cp = 64 * pass + kNB * k;
+    double4_t tv;
+    apply_panel_to_strip_pipelined<DT, LDV>(X, Vx + k * kNB * LDV, TfS + k * kNB * kNB, sclS + k * kNB, t0_tile(j0, cp, r, g), tv, r, g);
+    tv = transpose_groups(tv);  // lane (r, g): columns cp + 4 g .. cp + 4 g + 3 of row j0 + r
+    const bool direct = is_direct(pass);
+    const double osc = direct ? pS[(j0 + r) / d] : 1.0;
+    const double2 lo2{osc * tv[0], osc * tv[1]}, hi2{osc * tv[2], osc * tv[3]};
+    if (direct) {  // strip order of the state factor: two pairs per lane, 16 lanes of a pair contiguous
+      double* base = Ldst + tiled_index<DT>(j0 + r, cp + 4 * g);
+      *reinterpret_cast<double2*>(base) = lo2;
+      *reinterpret_cast<double2*>(base + 128) = hi2;  // next pair: + 64 lanes x 2 doubles
+    } else {
+      double* Trow = T + size_t(j0 + r) * D + cp + 4 * g;
+      *reinterpret_cast<double2*>(Trow) = lo2;
+      *reinterpret_cast<double2*>(Trow + 2) = hi2;
+    }
+    st.mark(2);
+  };
+
+  // Prologue: the wavefronts of group A start with the strips of block 0, those of group B with block 1, to which they apply
+  // the panels of pass 0 as they come. After that both groups run the same straight loop over THEIR passes P = gi, gi + 2, ..
+  // (one straight body: with the two roles as the arms of a branch inside the loop the register allocator keeps part of the
+  // 128-register strip in scratch around the join).
+  st.start();
+  load_strip(4 * gi + j, true);
+  st.mark(0);
+  if (gi == 1) {
+#pragma unroll 1
+    for (int k = 0; k < 4; ++k) {
+      apply_panel(0, k, 4 + j);
+      bump(&freeS[k]);
+    }
+  }
+#pragma unroll 1
+  for (int P = gi; P < NBLK; P += 2) {
+    const bool has_trailing = P + 2 < NBLK;
+    const int mystrip = 4 * P + j;
+    // ================= chain of pass P: the panels before mine, then my strip becomes panel j
+    // (unrolled with guards: as a loop with a run-time trip count, with the strip live into and out of it, the register allocator
+    // parks the strip in scratch)
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk) {
+      if (kk < j) {
+        apply_panel(P, kk, mystrip);
+        if (!has_trailing) bump(&freeS[kk]);
+      }
+    }
+    {
+      const int cp = 64 * P + kNB * j;
+      const int r = opaque(lane & 15), g = opaque(lane >> 4);
+      const double alpha = sigma * K.qsT[cp / d][cp / d];
+      double tfrow[kNB], myscl = 0.0;
+#pragma unroll
+      for (int m = 0; m < kNB; ++m) tfrow[m] = 0.0;
+      double* tpp_row = TppS + j * kNB * kNB + r * kNB;
+      __builtin_amdgcn_s_setprio(3);
+      pivot_sweep<0, DT>(X, tfrow, tpp_row, myscl, alpha, r);
+      __builtin_amdgcn_s_setprio(0);
+      st.mark(3);
+      if (P > 0) spin_ge(&freeS[j], 8 * P);  // every wavefront is done with this slot's panel of the previous pass
+      st.mark(4);
+      double* Vp = Vx + j * kNB * LDV;
+#pragma unroll
+      for (int T4 = 0; T4 < DT / 4; ++T4)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) Vp[r * LDV + 64 * T4 + 16 * g + e] = X[16 * T4 + e];
+      if (g == 0) {
+        sclS[j * kNB + r] = myscl;
+#pragma unroll
+        for (int m = 0; m < kNB; ++m) TfS[j * kNB * kNB + r * kNB + m] = tfrow[m];
+      }
+      lds_done();
+      if (lane == 0) *(volatile lds_int*)&pubS[j] = P + 1;
+      {
+        // diagonal block of T: lane (r, g) writes columns 4g .. 4g+3 of row r (zeros above the diagonal)
+        double o4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o4[q] = tpp_row[4 * g + q];
+        const int row = cp + r;
+        const bool direct = is_direct(P);
+        const double osc = direct ? pS[row / d] : 1.0;
+#pragma unroll
+        for (int q = 0; q < 4; q += 2) {
+          const double2 t2{osc * o4[q], osc * o4[q + 1]};
+          double* dstp = direct ? Ldst + tiled_index<DT>(row, cp + 4 * g + q) : T + size_t(row) * D + cp + 4 * g + q;
+          *reinterpret_cast<double2*>(dstp) = t2;  // (4 g + q is even: the pair is contiguous in both layouts)
+        }
+      }
+      st.mark(5);
+    }
+    if (!has_trailing) {
+#pragma unroll 1
+      for (int k = j; k < 4; ++k) bump(&freeS[k]);  // (slots I never read in this pass)
+    }
+    // ================= the other blocks of pass P: strip j of the blocks P + 3 .. goes back to HBM, strip j of block P + 2 stays
+#pragma unroll 1
+    for (int blk = NBLK - 1; blk >= P + 2; --blk) {
+      if (P > 0) {
+        spin_ge(&storedS[j], P);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      }
+      load_strip(4 * blk + j, P == 0);
+      st.mark(0);
+#pragma unroll 1
+      for (int k = 0; k < 4; ++k) {
+        apply_panel(P, k, 4 * blk + j);
+        if (blk == P + 2) bump(&freeS[k]);
+      }
+      if (blk != P + 2) store_strip(4 * blk + j);
+      st.mark(6);
+    }
+    if (NBLK - 1 >= P + 3) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // my stores have left before the flag moves
+      if (lane == 0) *(volatile lds_int*)&storedS[j] = P + 1;
+    }
+    // ================= the panels of pass P + 1 (the other group's chain) on strip j of block P + 2, my next panel
+    if (has_trailing) {
+#pragma unroll 1
+      for (int k = 0; k < 4; ++k) {
+        apply_panel(P + 1, k, 4 * (P + 2) + j);
+        bump(&freeS[k]);
+      }
+    }
+  }
+#ifdef PNODE_TIMING_BUILD
+  if (lane == 0) {
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(v.S + size_t(b) * d * d) + wv * 8;
+    for (int i = 0; i < 8; ++i) dbg[i] = st.acc[i];
+  }
+#endif
+  if (*abort_word) {
+    // a wait ran into its limit: make the failure visible in every output of the step
+    for (int i = lane; i < D * D; i += 64) {
+      T[i] = __builtin_nan("");
+      Ldst[i] = __builtin_nan("");
+    }
+  }
+}
+
+bool dense_lq4_supported(const DenseView& v) {
+  const int DT = v.D / 16, DD = v.d / 16;
+  return v.d % 16 == 0 && ((DT == 8 && DD == 2) || (DT == 12 && DD == 2) || (DT == 16 && DD == 4));
+}
+
+void dense_launch_lq4(const DenseView& v, const StepArg* args, const IwpConst* K, hipStream_t s) {
+  switch (v.D / 16) {
+    case 8: hipLaunchKernelGGL((dense_lq4_mfma_kernel<8, 2>), dim3(v.B), dim3(512), 0, s, v, args, K); break;
+    case 12: hipLaunchKernelGGL((dense_lq4_mfma_kernel<12, 2>), dim3(v.B), dim3(512), 0, s, v, args, K); break;
+    case 16: hipLaunchKernelGGL((dense_lq4_mfma_kernel<16, 4>), dim3(v.B), dim3(512), 0, s, v, args, K); break;
+    default: break;
+  }
+}
+
+}  // namespace pnode

@@ -884,10 +884,8 @@ static void launch_mfma(const DenseView& v, const StepArg* args, const IwpConst*
     if (ev) (void)hipEventRecord(ev->ev[i], s);
   };
   mark(2);
-  if (v.lq_one_launch == 2 && dense_lqc_supported(v)) {
-    dense_launch_lqc(v, args, K, s);  // one launch, column-split wavefront groups (pnode_dense_lqc.hip)
-  } else if (v.lq_one_launch == 1 && dense_lq3_supported(v)) {
-    dense_launch_lq3(v, args, K, s);  // one launch, 64-row passes, register-resident panels (pnode_dense_lq.hip)
+  if (!v.lq_two_launch && dense_lq4_supported(v)) {
+    dense_launch_lq4(v, args, K, s);  // one launch, overlapping 64-row passes (pnode_dense_lq4.hip)
   } else {
     hipLaunchKernelGGL((dense_lq2_mfma_kernel<DT, true>), dim3(v.B), dim3(256), 0, s, v, args, K, 0);
     hipLaunchKernelGGL((dense_lq2_mfma_kernel<DT, false>), dim3(v.B), dim3(256), 0, s, v, args, K, 1);

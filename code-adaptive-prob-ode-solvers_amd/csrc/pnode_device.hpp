@@ -42,8 +42,8 @@ struct DenseView {
   int B, d, k, n, D, K;
   int ts1, dynamic, vf_id, P, prm_per_traj;
   int force_generic;  // 1: never take the MFMA fast path (A/B testing)
-  int lq_one_launch;  // LQ of the MFMA fast path. 0: two launches, 32-row passes (pnode_dense_mfma.hip); 1: one launch, 64-row
-                      // passes, one wavefront per panel (pnode_dense_lq.hip); 2: one launch, column-split groups (pnode_dense_lqc.hip)
+  int lq_two_launch;  // 1: LQ of the MFMA fast path by the two-launch, 32-row-pass kernels (pnode_dense_mfma.hip) even where the
+                      // one-launch kernel with overlapping 64-row passes (pnode_dense_lq4.hip) supports the shape (A/B testing)
   double* mean;   // [3][B][n][d]
   double* U;      // [3][B][D][D]   Sigma = U^T U (row-major)
   double* sigma;  // [3][B]
@@ -92,21 +92,9 @@ struct DenseView {
   double* lgXi;          // [B][D]
 };
 
-// Who holds which 16-row strip when, in the one-launch LQ of the MFMA fast path (pnode_dense_lq.hip): built on the host,
-// passed to the kernel by value. Strip numbers are global (row / 16); -1 = nothing.
-constexpr int kLqWaves = 8, kLqMaxPass = 10, kLqMaxRounds = 3, kLqMaxNP = 4;
-struct LqSchedule {
-  int8_t npass, np, dt, pad;
-  int8_t pw[kLqMaxPass][kLqMaxNP];                   // wavefront that holds (and factorises) panel k of pass P
-  int8_t shadow[kLqMaxPass][kLqWaves];               // strip a non-panel wavefront holds while the panels of pass P are factorised
-  int8_t nrounds[kLqMaxPass];
-  int8_t round[kLqMaxPass][kLqMaxRounds][kLqWaves];  // strips processed after the last panel of pass P is published
-};
-bool lq_build_schedule(int DT, int NP, LqSchedule* S);
-bool dense_lq3_supported(const DenseView& v);
-void dense_launch_lq3(const DenseView& v, const StepArg* args, const IwpConst* K, hipStream_t s);
-bool dense_lqc_supported(const DenseView& v);
-void dense_launch_lqc(const DenseView& v, const StepArg* args, const IwpConst* K, hipStream_t s);
+// One-launch LQ of the MFMA fast path (pnode_dense_lq4.hip)
+bool dense_lq4_supported(const DenseView& v);
+void dense_launch_lq4(const DenseView& v, const StepArg* args, const IwpConst* K, hipStream_t s);
 
 // Optional per-phase timing of one dense step: events[0..4] bracket begin | lq_input | lq | correct.
 struct PhaseEvents {

@@ -133,4 +133,95 @@ __device__ __forceinline__ void apply_panel_to_strip(double (&X)[4 * DT], const 
   }
 }
 
+// The same, with the LDS operand reads software-pipelined in groups of eight: the reads of group h + 1 are in flight while the
+// matrix core works on group h (8 x 64 cycles, longer than an LDS round trip under load, 300-400 cycles). In the version above
+// every 64-column super-tile starts with its 16 reads exposed (the scheduling barrier that bounds the register pressure also
+// stops the prefetch): eight exposed round trips per application, a quarter of its run time when the wavefront has the SIMD to itself.
+template <int DT, int LDV>
+__device__ __forceinline__ void apply_panel_to_strip_pipelined(double (&X)[4 * DT], const double* __restrict__ Vp,
+                                                               const double* __restrict__ Tfp, const double* __restrict__ sclp,
+                                                               double4_t t0v, double4_t& tvals, int r, int g) {
+  constexpr int NG = DT / 2;  // groups of 8 operands: half a super-tile
+  double4_t a0 = {0.0, 0.0, 0.0, 0.0}, a1 = a0, a2 = a0, a3 = a0;
+  double va[8], vb[8];
+  // ---- G = X V^T: group h = (T, half): operands V[r][64 T + 16 g + 8 half + e], e = 0..7
+  const double* vbase = Vp + r * LDV + 16 * g;
+  auto load_g = [&](double (&dst)[8], int h) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dst[e] = vbase[64 * (h >> 1) + 8 * (h & 1) + e];
+  };
+  auto mfma_g = [&](const double (&src)[8], int h) {
+    const int xo = 16 * (h >> 1) + 8 * (h & 1);
+    // (column 4 i + q of the half goes to accumulator i' = 2 (h & 1) + i: the same four chains as the plain version)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (h & 1) {
+        a2 = MFMA64(src[q], X[xo + q], a2);
+        a3 = MFMA64(src[4 + q], X[xo + 4 + q], a3);
+      } else {
+        a0 = MFMA64(src[q], X[xo + q], a0);
+        a1 = MFMA64(src[4 + q], X[xo + 4 + q], a1);
+      }
+    }
+  };
+  load_g(va, 0);
+#pragma unroll
+  for (int h = 0; h < NG; h += 2) {
+    load_g(vb, h + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_g(va, h);
+    __builtin_amdgcn_sched_barrier(0);
+    if (h + 2 < NG) load_g(va, h + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_g(vb, h + 1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  double4_t sc;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) sc[q] = sclp[g + 4 * q];
+  double tf4[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) tf4[kk] = Tfp[(4 * kk + g) * kNB + r];
+  // ---- update operands of the first group are requested before the small W = G Tf product
+  const int coff = 16 * (r & 3) + (r >> 2);
+  const double* ubase = Vp + g * LDV + coff;
+  auto load_u = [&](double (&dst)[8], int h) {  // group h = tiles (T, j) = (h / 2, 2 (h & 1) + {0, 1}), four reflector groups kk each
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) dst[4 * t + kk] = ubase[4 * kk * LDV + 64 * (h >> 1) + 4 * (2 * (h & 1) + t)];
+  };
+  load_u(va, 0);
+  const double4_t acc = t0v + ((a0 + a1) + (a2 + a3)) * sc;  // G = T0 + (X raw^T) diag(scl)
+  double4_t w4 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) w4 = MFMA64(tf4[kk], acc[kk], w4);
+  tvals = t0v - w4;
+  w4 = w4 * sc;  // the update below multiplies by the unscaled rows
+  auto mfma_u = [&](const double (&src)[8], int h) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int xo = 16 * (h >> 1) + 4 * (2 * (h & 1) + t);
+      double4_t c4 = {X[xo], X[xo + 1], X[xo + 2], X[xo + 3]};
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) c4 = MFMA64(-src[4 * t + kk], w4[kk], c4);
+      X[xo] = c4[0];
+      X[xo + 1] = c4[1];
+      X[xo + 2] = c4[2];
+      X[xo + 3] = c4[3];
+    }
+  };
+#pragma unroll
+  for (int h = 0; h < NG; h += 2) {
+    load_u(vb, h + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_u(va, h);
+    __builtin_amdgcn_sched_barrier(0);
+    if (h + 2 < NG) load_u(va, h + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_u(vb, h + 1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 }  // namespace pnode

@@ -24,7 +24,7 @@ SYMBOLS = (
     "pnode_set_tolerances pnode_attempt_step pnode_user_extrapolate pnode_user_set_vf pnode_commit pnode_interpolate pnode_checkpoint_at_step "
     "pnode_solve_fixed_grid pnode_solve_adaptive_save_at pnode_solve_adaptive_save_at_device pnode_read_mean pnode_read_time pnode_read_output_scale pnode_read_factor "
     "pnode_read_checkpoint_means pnode_read_checkpoint_factors pnode_smooth_checkpoint_means pnode_last_step_ms pnode_set_phase_timing "
-    "pnode_last_phase_ms pnode_set_generic_path pnode_stream pnode_lq_schedule pnode_advance_device"
+    "pnode_last_phase_ms pnode_set_generic_path pnode_stream pnode_advance_device"
 ).split()
 
 
@@ -63,7 +63,7 @@ class PnodeConfig(C.Structure):
 _lib = None
 
 # A/B testing of the dense device paths through the high-level API: every dense Batch created while this is non-zero
-# calls pnode_set_generic_path with it (1 = generic kernels, 2 = large-D kernels, 3 = MFMA kernels with the one-launch LQ).
+# calls pnode_set_generic_path with it (1 = generic kernels, 2 = large-D kernels, 3 = MFMA kernels with the two-launch LQ).
 # Tests set it with monkeypatch.setattr; nothing reads the environment.
 dense_path = 0
 
@@ -119,7 +119,6 @@ def load_library():
     lib.pnode_offgrid_means.argtypes = [vp, i32p, dp, C.c_int32, dp, dp, dp, i32p, u8p, dp]
     lib.pnode_sample_checkpoints.argtypes = [vp, i32p, C.c_int32, dp, dp]
     lib.pnode_advance_device.argtypes = [vp, dp, dp, dp, C.POINTER(PnodeControl), C.c_double, C.c_int32, i32p, i64p]
-    lib.pnode_lq_schedule.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_int8), C.c_int32]
     lib.pnode_stream.restype = vp
     for name in SYMBOLS:
         if name not in ("pnode_last_error", "pnode_stream"):
@@ -393,20 +392,6 @@ class Batch:
         ms = C.c_float()
         _check(self._lib.pnode_last_step_ms(self._h, C.byref(ms)))
         return float(ms.value)
-
-
-def lq_schedule(num_strips, panels_per_pass=4):
-    """The strip schedule of the one-launch LQ kernel as a dict of arrays (host-only; see include/pnode.h)."""
-    waves, max_pass, max_rounds, max_np = 8, 10, 3, 4
-    buf = np.zeros(4 + max_pass * (max_np + waves + 1 + max_rounds * waves), dtype=np.int8)
-    n = _check(load_library().pnode_lq_schedule(num_strips, panels_per_pass, buf.ctypes.data_as(C.POINTER(C.c_int8)), buf.size))
-    assert n == buf.size, (n, buf.size)
-    o = 4
-    pw = buf[o:o + max_pass * max_np].reshape(max_pass, max_np); o += max_pass * max_np
-    shadow = buf[o:o + max_pass * waves].reshape(max_pass, waves); o += max_pass * waves
-    nrounds = buf[o:o + max_pass]; o += max_pass
-    rounds = buf[o:o + max_pass * max_rounds * waves].reshape(max_pass, max_rounds, waves)
-    return {"npass": int(buf[0]), "np": int(buf[1]), "dt": int(buf[2]), "pw": pw, "shadow": shadow, "nrounds": nrounds, "round": rounds}
 
 
 def device_count():

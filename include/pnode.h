@@ -211,7 +211,8 @@ int pnode_last_step_ms(pnode_batch* h, float* ms_out);
 /* Dense model only, A/B testing of the device paths (all of them HIP, none a CPU fallback): 0 = dispatch by shape
  * (fused one-wavefront kernel for (nu+1)*d <= 32, register-resident MFMA kernels, HBM-tiled large-D kernels, generic
  * kernels otherwise), 1 = generic kernels, 2 = large-D kernels (PNODE_EINVAL if the shape is not supported there),
- * 3 = MFMA kernels with the one-launch LQ (64-row passes, csrc/pnode_dense_lq.hip) instead of the two-launch LQ.
+ * 3 = MFMA kernels with the two-launch LQ (32-row passes, csrc/pnode_dense_mfma.hip) instead of the one-launch LQ with
+ * overlapping 64-row passes (csrc/pnode_dense_lq4.hip), which is what 0 selects for (nu+1)*d = 128, 192, 256.
  * The choice must be made before the first step after pnode_set_initial (PNODE_ESTATE afterwards): the paths keep the state
  * factor in different layouts.
  * No environment variable influences the library: the choice is per handle, through this call only. */
@@ -231,12 +232,6 @@ void* pnode_stream(pnode_batch* h);
  * beyond (nu+1) d = 32 (strategy_filter); bench.py uses it for the timed region of the headline. */
 int pnode_advance_device(pnode_batch* h, const double* t_stop, double* dt_inout, double* log_err_prev_inout, const pnode_control* ctrl,
                          double numerical_zero, int32_t rounds, int32_t* status_out, int64_t* attempts_out);
-/* Host-only (no GPU needed): the table that tells the one-launch LQ kernel of the MFMA fast path which wavefront holds which
- * 16-row strip when (csrc/pnode_device.hpp: LqSchedule), for num_strips = D/16 strips and panels_per_pass panels per pass.
- * Writes the table to out (capacity bytes) and returns its size; PNODE_EINVAL if no table exists for the shape. Lets the
- * CPU tests check the invariants the kernel relies on (every strip processed once per pass, a strip that becomes a panel
- * of the next pass stays with the wavefront that will factorise it). */
-int pnode_lq_schedule(int32_t num_strips, int32_t panels_per_pass, int8_t* out, int32_t capacity);
 
 #ifdef __cplusplus
 }

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """In-kernel s_memtime stamps of the one-launch LQ kernel. Needs the DIAGNOSTIC library (`make -C csrc timing` ->
 libpnode_hip_timing.so, compiled with -DPNODE_TIMING_BUILD); the shipped library contains no stamps.
-  python scripts/lq_phase_stamps.py [B] [PATH]      PATH 3: one wavefront per panel (default), 4: column-split groups"""
+  python scripts/lq_phase_stamps.py [B]"""
 import ctypes as C, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -19,15 +19,12 @@ y0 = np.stack([brusselator_y0(N, 0.1 * b) for b in range(B)])
 tc = np.stack(tcoeffs(vf, [y0], nu), axis=1)
 bt = _backend.Batch(batch=B, d=vf.d, nu=nu, ode_order=1, model="dense", correction="ts1", strategy="filter",
                     calibration="dynamic", vf_id=vf.vf_id, vf_params=vf.param_array(), num_checkpoints=2)
-PATH = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-bt.set_generic_path(PATH)  # a one-launch LQ
 bt.set_initial(tc, np.zeros(B), np.ones(B))
 bt.set_tolerances(1e-6, 1e-6)
 err, one = np.zeros(B), np.ones(B, np.uint8)
 lib = bt._lib
 lib.pnode_debug_read_scratch.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint64)]
-names = (["load", "apply(chain)", "sweep", "publish", "barrier(chain)", "apply(after)", "store", "barrier(end)"] if PATH == 3 else
-         ["other", "pivot:dot", "pivot:exchange", "pivot:math+Tf", "pivot:update", "apply:G", "apply:exchange", "apply:W+update"])
+names = ["load", "wait panel", "apply", "sweep", "wait slot", "publish", "store", "-"]
 for it in range(3):
     bt.attempt_step(np.full(B, 0.005), one, err)
     bt.commit(one)

@@ -214,19 +214,19 @@ def test_dense_steps_match_oracle(hip_lib, case, path):
     batch.close()
 
 
-@pytest.mark.parametrize("case", ["small", "mfma", "onelq", "large", "generic"])
+@pytest.mark.parametrize("case", ["small", "mfma", "twolq", "large", "generic"])
 def test_dense_inactive_and_rejected_trajectories_untouched(hip_lib, case):
     """Every dense device path: an inactive trajectory keeps its state and error slot bit for bit, a rejected attempt
     leaves STEP_FROM intact (the next attempt from the same state reproduces the same numbers), an accepted one advances."""
     if case == "small":
         vf, nu, y0 = V.rigid_body(), 3, np.array([[1.0, 0.0, 0.9], [0.9, 0.1, 0.8], [1.1, -0.1, 1.0]])
     else:
-        N = {"mfma": 16, "onelq": 16, "large": 48, "generic": 12}[case]
+        N = {"mfma": 16, "twolq": 16, "large": 48, "generic": 12}[case]
         vf, nu, y0 = V.brusselator(N), 3, np.stack([brusselator_y0(N, ph) for ph in (0.0, 0.3, 0.6)])
     B = 3
     tc = np.stack(tcoeffs(vf, [y0], nu), axis=1)
     batch = _dense_batch(vf, nu, "ts1", B)
-    if case == "onelq":
+    if case == "twolq":
         batch.set_generic_path(3)
     batch.set_initial(tc, np.zeros(B), np.ones(B))
     batch.set_tolerances(1e-5, 1e-5)
@@ -247,7 +247,7 @@ def test_dense_inactive_and_rejected_trajectories_untouched(hip_lib, case):
     batch.close()
 
 
-LQ_PATHS = {"two_launch": 0, "one_launch": 3, "column_split": 4}  # pnode_set_generic_path values of the MFMA path's LQ kernels
+LQ_PATHS = {"one_launch": 0, "two_launch": 3}  # pnode_set_generic_path values that select the LQ kernel of the MFMA path
 
 
 @pytest.mark.parametrize("lq", list(LQ_PATHS))
@@ -255,8 +255,8 @@ LQ_PATHS = {"two_launch": 0, "one_launch": 3, "column_split": 4}  # pnode_set_ge
 def test_dense_mfma_path_matches_oracle_and_generic(hip_lib, N, nu, lq):
     """The MFMA-tiled LQ / measurement-update kernels (d % 16 == 0) against the oracle and against the
     generic HIP kernels, over several consecutive steps with growing covariance. Both time-update kernels of the MFMA path:
-    the two-launch LQ with 32-row passes (default) and the one-launch LQ with 64-row passes and register-resident panel
-    factorisation (csrc/pnode_dense_lq.hip; D = 128, 192, 256)."""
+    the one-launch LQ with overlapping 64-row passes and register-resident panel factorisation (csrc/pnode_dense_lq4.hip,
+    the default at D = 128, 192, 256) and the two-launch LQ with 32-row passes (csrc/pnode_dense_mfma.hip)."""
     vf = V.brusselator(N)
     B = 3
     y0 = np.stack([brusselator_y0(N, ph) for ph in (0.0, 0.4, 1.1)])
@@ -742,7 +742,7 @@ def test_user_vector_field_escape_hatch(hip_lib):
             assert relmax(sol.u[b], osol.u) < 1e-6
 
 
-@pytest.mark.parametrize("case", ["small_rigid", "small_vdp2", "mfma16", "mfma32", "onelq16", "onelq32", "large16", "large48"])
+@pytest.mark.parametrize("case", ["small_rigid", "small_vdp2", "mfma16", "mfma32", "twolq16", "twolq32", "large16", "large48"])
 def test_differential_fuzz_fast_paths_against_generic_kernels(hip_lib, case):
     """Seeded differential run of every fast dense path against the generic kernels: 25 attempts with random step sizes,
     random activity masks and random accept/reject decisions (slots drift apart, rejected states are re-used). The two
@@ -762,8 +762,8 @@ def test_differential_fuzz_fast_paths_against_generic_kernels(hip_lib, case):
     fast = _dense_batch(vf, nu, "ts1", B)
     if case.startswith("large"):
         fast.set_generic_path(2)
-    if case.startswith("onelq"):
-        fast.set_generic_path(3)  # MFMA kernels with the one-launch LQ
+    if case.startswith("twolq"):
+        fast.set_generic_path(3)  # MFMA kernels with the two-launch LQ
     slow = _dense_batch(vf, nu, "ts1", B)
     slow.set_generic_path(1)
     for bt in (fast, slow):

@@ -249,45 +249,3 @@ def test_two_rank_sharded_solve_and_gather_equals_single_process(tmp_path):
     assert np.array_equal(np.load(tmp_path / "steps.npy"), steps_ref)
 
 
-@pytest.mark.parametrize("dt,np_", [(8, 4), (12, 4), (16, 4), (20, 2), (16, 2), (4, 4)])
-def test_lq_strip_schedule_invariants(dt, np_):
-    """The table that drives the one-launch LQ kernel of the MFMA fast path (csrc/pnode_dense_lq.hip), host logic only: in
-    every pass each trailing strip is processed exactly once, a wavefront never holds two strips at a time, and a strip that
-    becomes a panel of the next pass is processed LAST by its wavefront and names that wavefront as the panel owner."""
-    from probdiffeq_hip import _backend
-
-    S = _backend.lq_schedule(dt, np_)
-    npass = S["npass"]
-    assert npass == dt // np_ and S["np"] == np_ and S["dt"] == dt
-    assert list(S["pw"][0][:np_]) == list(range(np_))
-    for P in range(npass):
-        pw = [int(w) for w in S["pw"][P][:np_]]
-        assert len(set(pw)) == np_ and all(0 <= w < 8 for w in pw)
-        trailing = list(range(np_ * (P + 1), dt))
-        carried = [s for s in trailing if s < np_ * (P + 2)] if P + 1 < npass else []
-        seen, holding = [], {}
-        for w in range(8):
-            s = int(S["shadow"][P][w])
-            if s >= 0:
-                assert w not in pw, "a panel wavefront holds its panel while the pass is factorised"
-                seen.append(s)
-                if s in carried:
-                    holding[w] = s
-        for rd in range(int(S["nrounds"][P])):
-            for w in range(8):
-                s = int(S["round"][P][rd][w])
-                if s >= 0:
-                    assert w not in holding, "a wavefront that keeps a strip for the next pass takes no further strip"
-                    seen.append(s)
-                    if s in carried:
-                        holding[w] = s
-        for rd in range(int(S["nrounds"][P]), 3):
-            assert np.all(S["round"][P][rd] == -1)
-        assert sorted(seen) == trailing
-        if P + 1 < npass:
-            assert sorted(holding.values()) == carried
-            nxt = [int(w) for w in S["pw"][P + 1][:np_]]
-            for w, s in holding.items():
-                assert nxt[s - np_ * (P + 1)] == w
-    with pytest.raises(ValueError):
-        _backend.lq_schedule(10, 4)
