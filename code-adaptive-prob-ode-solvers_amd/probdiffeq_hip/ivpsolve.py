@@ -293,6 +293,8 @@ def solve_adaptive_save_at(vector_field, initial_condition: InitialCondition, sa
     if loop.failed.any():
         for b in np.nonzero(loop.failed)[0]:
             means[b, cursor[b]:] = np.nan
+            if cursor[b] <= 1:  # failed before its first checkpoint: the backward pass had nothing to start from and left
+                means[b, 0] = init.tcoeffs[b]  # the zero-initialised output; the value at t0 is the initial mean
     sol = _finish(means, init, solver.strategy.kind, batch, sa if sa.ndim == 1 else sa_b, num_steps, loop,
                   not init.batched)
     sol.posterior.index = None if init.batched else 0

@@ -300,13 +300,15 @@ def test_dense_mfma_path_matches_oracle_and_generic(hip_lib, N, nu, lq):
     slow.close()
 
 
-@pytest.mark.parametrize("N,nu", [(16, 3), (32, 3), (64, 3), (16, 5), (48, 2)])
+@pytest.mark.parametrize("N,nu", [(16, 3), (32, 3), (64, 3), (16, 5), (48, 2), (96, 2), (112, 3)])
 def test_dense_large_path_matches_oracle_and_mfma_path(hip_lib, N, nu):
     """The HBM-tiled large-D kernels (batched MFMA GEMMs, blocked LQ / Cholesky / triangular solve; the path BASELINE
     config 5 takes at D = 1024) forced at sizes the oracle steps through quickly: several steps with per-trajectory
     step sizes, a rejected step (destination slots drift apart) and an inactive trajectory, against the oracle and the
     default path. (16, 5): D = 192 = 128 + 64, a shorter last outer block; (48, 2): d = 96, D = 288 is not a multiple of
-    64 -> not supported there, the generic kernels are compared instead.)"""
+    64 -> not supported there, the generic kernels are compared instead; (96, 2): D = 576 and (112, 3): D = 896 are the sizes
+    whose K does not split into whole 256-column slices -- the split-K of the in-block G GEMM must fall back to 3 x 192
+    resp. one slice (round-1 advisor finding).)"""
     vf = V.brusselator(N)
     B = 3
     y0 = np.stack([brusselator_y0(N, ph) for ph in (0.0, 0.4, 1.1)])
@@ -329,7 +331,9 @@ def test_dense_large_path_matches_oracle_and_mfma_path(hip_lib, N, nu):
     el, er = np.zeros(B), np.zeros(B)
     plan = [(0.01, [1, 1, 1], [1, 1, 1]), (0.02, [1, 1, 1], [1, 0, 1]), (0.015, [1, 1, 0], [1, 1, 0]), (0.03, [1, 1, 1], [1, 1, 1])]
     for it, (dt0, active, accept) in enumerate(plan):
-        dts = dt0 * (1.0 + 0.2 * np.arange(B))
+        # (N >= 96: the diffusion term is N^2-stiff; with the full step sizes the EKF1 steps overshoot to |u| ~ 10^3 and the
+        # comparison measures the conditioning of an unstable trajectory)
+        dts = dt0 * (1.0 + 0.2 * np.arange(B)) * (0.25 if N >= 96 else 1.0)
         act = np.array(active, np.uint8)
         acc = np.array(accept, np.uint8)
         large.attempt_step(dts, act, el)
@@ -349,6 +353,8 @@ def test_dense_large_path_matches_oracle_and_mfma_path(hip_lib, N, nu):
                 continue
             for i in range(nu + 1):
                 tol_i = 1e-11 if i == 0 else (1e-9 if i == 1 else (1e-6 if nu <= 4 else 1e-4))
+                if N >= 96 and i == 0:
+                    tol_i = 2e-10
                 assert relmax(ml[b, i], new.mean[i]) < tol_i, (it, b, i)
                 assert relmax(ml[b, i], mr[b, i]) < tol_i, (it, b, i)
             # nu = 7: the covariance spans 20 orders of magnitude; the comparison is conditioning-limited
@@ -693,6 +699,16 @@ def test_edge_cases_single_checkpoint_ragged_save_at_and_nan_propagation(hip_lib
     assert abs(sol.u[0, -1, 0] - ex(0.1, 2.0)) < 1e-4 and abs(sol.u[2, -1, 0] - ex(0.3, 3.0)) < 1e-4
     # the diverging member (blow-up at t = log(6/5) ~ 0.18) never reaches its later checkpoints
     assert not np.all(np.isfinite(sol.u[1])) or sol.num_steps[1, -1] == 0 or np.max(np.abs(sol.u[1])) > 1e3
+    # the same batch with the fixed-point smoother: the member that fails before its first checkpoint has no backward pass to
+    # run; it reports its initial value at t0 (not the zero-initialised output buffer) and NaN afterwards
+    fp = ivpsolvers.solver_dynamic(ivpsolvers.strategy_fixedpoint(ivpsolvers.prior_ibm(2), ivpsolvers.correction_ts0()))
+    sol = ivpsolve.solve_adaptive_save_at(vfb, fp.initial_condition(tcs, 1.0), save_at=save_at, dt0=0.05,
+                                          adaptive_solver=ivpsolve.adaptive(fp, atol=1e-8, rtol=1e-6))
+    assert abs(sol.u[0, -1, 0] - ex(0.1, 2.0)) < 1e-4 and abs(sol.u[2, -1, 0] - ex(0.3, 3.0)) < 1e-4
+    if sol.num_steps[1, 1] == 0:  # (failed inside the first interval, as the blow-up time says it must)
+        assert sol.u[1, 0, 0] == 1.0 and np.all(np.isnan(sol.u[1, 1:]))
+    else:
+        assert not np.all(np.isfinite(sol.u[1])) or np.max(np.abs(sol.u[1])) > 1e3
 
 
 def test_user_vector_field_escape_hatch(hip_lib):
