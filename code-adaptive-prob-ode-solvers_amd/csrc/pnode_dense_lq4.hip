@@ -11,10 +11,14 @@
 //     of block P + 2 last: it is kept and is that wavefront's panel in pass P + 2).
 //   * The serial chain of the 4 D/64 x 4 sweeps, which bounds the kernel, therefore never waits for trailing updates, and at
 //     D = 256 only one 64-row block makes one round trip through HBM (none at D <= 192).
-//   * No workgroup barrier after the prologue. pubS[k] = P + 1: panel k of pass P is in LDS; freeS[k] counts the wavefronts
-//     that are done with slot k (8 per pass: the writer of the next pass waits for 8 (P + 1)); storedS[j]: strip j of the
-//     blocks parked in HBM by pass P. Every wait is a bounded spin (a wavefront that runs into the limit raises the abort word,
-//     all waits then fall through and the outputs of the trajectory are NaN).
+//   * Persistent workgroups, one per CU: each walks over the trajectories blockIdx.x, blockIdx.x + gridDim.x, .. and the passes
+//     of consecutive trajectories form ONE sequence (global pass G = NBLK it + P): group A loads and factorises block 0 of the
+//     next trajectory while group B is still in the last pass of the current one.
+//   * No workgroup barrier after the prologue. pubS[k] = G + 1: panel k of global pass G is in LDS; doneS[8 k + w] = G: wavefront w
+//     will not read slot k of any pass < G again (the writer of pass G waits for all eight; per-wavefront words, not a shared
+//     counter: a wavefront may be done with a slot of the running pass before the slowest one is done with the previous pass);
+//     storedS[j]: strip j of the blocks parked in HBM by pass G. Every wait is a bounded spin (a wavefront that runs into the
+//     limit raises the abort word, all waits then fall through and the outputs of the trajectory are NaN).
 //   * (A column-split variant -- four wavefronts sweeping a quarter of the columns each -- was measured and dropped: an LDS
 //     round trip costs 300-400 cycles under load, so the per-pivot exchange of the partial dot products, 850 cycles, outweighs
 //     the four times shorter DPP sweep.)
@@ -61,36 +65,41 @@ __global__ __launch_bounds__(512) void dense_lq4_mfma_kernel(const DenseView v, 
   __shared__ double Vx[4 * kNB * LDV];
   __shared__ double TfS[4 * kNB * kNB];
   __shared__ double sclS[4 * kNB];
-  __shared__ double TppS[4 * kNB * kNB];  // diagonal blocks of T, staged by the panel wavefront for a coalesced write
-  __shared__ double coef[kMaxN * kMaxN];
-  __shared__ double pS[kMaxN];
-  __shared__ int pubS[4], freeS[4], storedS[4];
+  __shared__ double TppS[8 * kNB * kNB];  // diagonal blocks of T, staged by the sweeping wavefront for a coalesced write (one region per
+                                          // wavefront: the sweeps of wavefronts j of the two groups overlap across trajectories)
+  __shared__ double coefS[2][kMaxN * kMaxN];  // per trajectory, double-buffered by the parity of the workgroup's trajectory count
+  __shared__ double pSS[2][kMaxN];
+  __shared__ int pubS[4], storedS[4];
+  __shared__ int doneS[4 * 8];  // doneS[8 k + w] = G: wavefront w will not read the content of slot k of any global pass < G again
+  __shared__ int prepS;  // number of trajectories whose coefS / pSS are written
   __shared__ int abortS;
 
-  const int b = blockIdx.x;
-  const StepArg sarg = args[b];
-  if (!sarg.active) return;
+  // PERSISTENT workgroups: the grid is one workgroup per CU (at most), each walks over the trajectories b = blockIdx.x,
+  // blockIdx.x + gridDim.x, .. WITHOUT a barrier in between: the passes of consecutive trajectories form one sequence (global
+  // pass number base + P), so group A loads and factorises block 0 of the next trajectory while group B is still in the last
+  // pass of the current one -- the tail of a trajectory (one group idle) overlaps the head of the next (the other group idle).
   const IwpConst& K = *Kc;
   const int nn = v.n;
-  const double sigma = v.sig_new[b];
-  double* __restrict__ Mt = v.M + size_t(b) * D * D;
-  double* __restrict__ T = v.R + size_t(b) * D * D;
-  const double* __restrict__ Lsrc = v.U + (size_t(sarg.src) * v.B + b) * D * D;
-  double* __restrict__ Ldst = v.U + (size_t(sarg.dst) * v.B + b) * D * D;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int gi = wv >> 2, j = wv & 3;
   if (tid == 0) {
-    // Mt = (Abar P^-1 (x) I) L is formed while the strips are read: coef[i][k] = Abar[i][k] / p_k
-    double pl[kMaxN], pil[kMaxN];
-    precond_rt(nn, sarg.dt, K, pl, pil);
-    for (int i = 0; i < nn; ++i)
-      for (int k = 0; k < nn; ++k) coef[i * kMaxN + k] = (k >= i) ? K.a[i][k] * pil[k] : 0.0;
-    for (int i = 0; i < kMaxN; ++i) pS[i] = (i < nn) ? pl[i] : 0.0;
-    for (int k = 0; k < 4; ++k) pubS[k] = freeS[k] = storedS[k] = 0;
+    for (int k = 0; k < 4; ++k) pubS[k] = storedS[k] = 0;
+    for (int k = 0; k < 32; ++k) doneS[k] = 0;
+    prepS = 0;
     abortS = 0;
   }
   __syncthreads();  // the only workgroup barrier
+  // per trajectory (set at the top of the trajectory loop; the lambdas below see them by reference)
+  int b = 0, base = 0;
+  StepArg sarg = args[blockIdx.x];
+  double sigma = 0.0;
+  double* __restrict__ Mt = nullptr;
+  double* __restrict__ T = nullptr;
+  const double* __restrict__ Lsrc = nullptr;
+  double* __restrict__ Ldst = nullptr;
+  const double* coef = coefS[0];
+  const double* pS = pSS[0];
 
   volatile lds_int* abort_word = (volatile lds_int*)&abortS;
   auto spin_ge = [&](int* f_, int target) {
@@ -106,9 +115,24 @@ __global__ __launch_bounds__(512) void dense_lq4_mfma_kernel(const DenseView v, 
     asm volatile("" ::: "memory");
   };
   auto lds_done = [] { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
-  auto bump = [&](int* f) {  // my LDS reads / writes issued so far have completed before the counter moves
+  // Slot bookkeeping by per-wavefront progress words (not a shared counter: a wavefront may be done with a slot of the running
+  // pass before the slowest one is done with the previous pass, and a counter cannot tell the two apart).
+  auto mark_done = [&](int k, int G) {  // my LDS reads issued so far have completed before the word moves
     lds_done();
-    if (lane == 0) __hip_atomic_fetch_add((lds_int*)f, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (lane == 0) *(volatile lds_int*)&doneS[8 * k + wv] = G;
+  };
+  auto wait_slot_free = [&](int k, int G) {  // every wavefront is done with slot k of the global passes < G
+    int n = 0;
+    while (true) {
+      const int mine = (lane < 8) ? *(volatile lds_int*)&doneS[8 * k + lane] : 0x7fffffff;
+      if (!__any(mine < G)) break;
+      __builtin_amdgcn_s_sleep(2);
+      if ((++n & 255) == 0 && (n > kSpinLimit || __builtin_amdgcn_readfirstlane(*abort_word))) {
+        *abort_word = 1;
+        break;
+      }
+    }
+    asm volatile("" ::: "memory");
   };
   // (lane coordinates made opaque per call site: otherwise every LDS / HBM address of every call is hoisted out of the pass
   // loop as a loop invariant and the hoisted addresses alone overflow the register file)
@@ -178,7 +202,7 @@ __global__ __launch_bounds__(512) void dense_lq4_mfma_kernel(const DenseView v, 
   // panel k of pass `pass` applied to my strip (global strip index st_), once it is published. (Raising the issue priority of
   // the applications the chain is waiting for changed nothing measurable.)
   auto apply_panel = [&](int pass, int k, int st_) {
-    spin_ge(&pubS[k], pass + 1);
+    spin_ge(&pubS[k], base + pass + 1);
     st.mark(1);
     const int r = opaque(lane & 15), g = opaque(lane >> 4);
     const int j0 = kNB * st_, cp = 64 * pass + kNB * k;
@@ -200,122 +224,158 @@ __global__ __launch_bounds__(512) void dense_lq4_mfma_kernel(const DenseView v, 
     st.mark(2);
   };
 
-  // Prologue: the wavefronts of group A start with the strips of block 0, those of group B with block 1, to which they apply
-  // the panels of pass 0 as they come. After that both groups run the same straight loop over THEIR passes P = gi, gi + 2, ..
-  // (one straight body: with the two roles as the arms of a branch inside the loop the register allocator keeps part of the
-  // 128-register strip in scratch around the join).
   st.start();
-  load_strip(4 * gi + j, true);
-  st.mark(0);
-  if (gi == 1) {
+  int it = 0;  // trajectories this workgroup has taken so far
 #pragma unroll 1
-    for (int k = 0; k < 4; ++k) {
-      apply_panel(0, k, 4 + j);
-      bump(&freeS[k]);
-    }
-  }
-#pragma unroll 1
-  for (int P = gi; P < NBLK; P += 2) {
-    const bool has_trailing = P + 2 < NBLK;
-    const int mystrip = 4 * P + j;
-    // ================= chain of pass P: the panels before mine, then my strip becomes panel j
-    // (unrolled with guards: as a loop with a run-time trip count, with the strip live into and out of it, the register allocator
-    // parks the strip in scratch)
-#pragma unroll
-    for (int kk = 0; kk < 3; ++kk) {
-      if (kk < j) {
-        apply_panel(P, kk, mystrip);
-        if (!has_trailing) bump(&freeS[kk]);
-      }
-    }
-    {
-      const int cp = 64 * P + kNB * j;
-      const int r = opaque(lane & 15), g = opaque(lane >> 4);
-      const double alpha = sigma * K.qsT[cp / d][cp / d];
-      double tfrow[kNB], myscl = 0.0;
-#pragma unroll
-      for (int m = 0; m < kNB; ++m) tfrow[m] = 0.0;
-      double* tpp_row = TppS + j * kNB * kNB + r * kNB;
-      __builtin_amdgcn_s_setprio(3);
-      pivot_sweep<0, DT>(X, tfrow, tpp_row, myscl, alpha, r);
-      __builtin_amdgcn_s_setprio(0);
-      st.mark(3);
-      if (P > 0) spin_ge(&freeS[j], 8 * P);  // every wavefront is done with this slot's panel of the previous pass
-      st.mark(4);
-      double* Vp = Vx + j * kNB * LDV;
-#pragma unroll
-      for (int T4 = 0; T4 < DT / 4; ++T4)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) Vp[r * LDV + 64 * T4 + 16 * g + e] = X[16 * T4 + e];
-      if (g == 0) {
-        sclS[j * kNB + r] = myscl;
-#pragma unroll
-        for (int m = 0; m < kNB; ++m) TfS[j * kNB * kNB + r * kNB + m] = tfrow[m];
+  for (b = blockIdx.x; b < v.B; b += gridDim.x) {
+    sarg = args[b];
+    if (!sarg.active) continue;  // (uniform over the workgroup)
+    base = NBLK * it;
+    sigma = v.sig_new[b];
+    Mt = v.M + size_t(b) * D * D;
+    T = v.R + size_t(b) * D * D;
+    Lsrc = v.U + (size_t(sarg.src) * v.B + b) * D * D;
+    Ldst = v.U + (size_t(sarg.dst) * v.B + b) * D * D;
+    coef = coefS[it & 1];
+    pS = pSS[it & 1];
+    if (wv == 0) {
+      // Mt = (Abar P^-1 (x) I) L is formed while the strips are read: coef[i][k] = Abar[i][k] / p_k. (Group A is at most one
+      // trajectory ahead of group B: the slot of the trajectory before last is free.)
+      if (lane == 0) {
+        double pl[kMaxN], pil[kMaxN];
+        precond_rt(nn, sarg.dt, K, pl, pil);
+        double* cw = coefS[it & 1];
+        double* pw = pSS[it & 1];
+        for (int i = 0; i < nn; ++i)
+          for (int k = 0; k < nn; ++k) cw[i * kMaxN + k] = (k >= i) ? K.a[i][k] * pil[k] : 0.0;
+        for (int i = 0; i < kMaxN; ++i) pw[i] = (i < nn) ? pl[i] : 0.0;
       }
       lds_done();
-      if (lane == 0) *(volatile lds_int*)&pubS[j] = P + 1;
-      {
-        // diagonal block of T: lane (r, g) writes columns 4g .. 4g+3 of row r (zeros above the diagonal)
-        double o4[4];
+      if (lane == 0) *(volatile lds_int*)&prepS = it + 1;
+    }
+    spin_ge(&prepS, it + 1);
+    // Prologue: the wavefronts of group A start with the strips of block 0, those of group B with block 1, to which they apply
+    // the panels of pass 0 as they come. After that both groups run the same straight loop over THEIR passes P = gi, gi + 2, ..
+    // (one straight body: with the two roles as the arms of a branch inside the loop the register allocator keeps part of the
+    // 128-register strip in scratch around the join).
+    load_strip(4 * gi + j, true);
+    st.mark(0);
+    if (gi == 1) {
+#pragma unroll 1
+      for (int k = 0; k < 4; ++k) {
+        apply_panel(0, k, 4 + j);
+        mark_done(k, base + 1);
+      }
+    }
+#pragma unroll 1
+    for (int P = gi; P < NBLK; P += 2) {
+      const bool has_trailing = P + 2 < NBLK;
+      const int mystrip = 4 * P + j;
+      // ================= chain of pass P: the panels before mine, then my strip becomes panel j
+      // (unrolled with guards: as a loop with a run-time trip count, with the strip live into and out of it, the register allocator
+      // parks the strip in scratch)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) o4[q] = tpp_row[4 * g + q];
-        const int row = cp + r;
-        const bool direct = is_direct(P);
-        const double osc = direct ? pS[row / d] : 1.0;
-#pragma unroll
-        for (int q = 0; q < 4; q += 2) {
-          const double2 t2{osc * o4[q], osc * o4[q + 1]};
-          double* dstp = direct ? Ldst + tiled_index<DT>(row, cp + 4 * g + q) : T + size_t(row) * D + cp + 4 * g + q;
-          *reinterpret_cast<double2*>(dstp) = t2;  // (4 g + q is even: the pair is contiguous in both layouts)
+      for (int kk = 0; kk < 3; ++kk) {
+        if (kk < j) {
+          apply_panel(P, kk, mystrip);
+          if (!has_trailing) mark_done(kk, base + P + 1);
         }
       }
-      st.mark(5);
-    }
-    if (!has_trailing) {
-#pragma unroll 1
-      for (int k = j; k < 4; ++k) bump(&freeS[k]);  // (slots I never read in this pass)
-    }
-    // ================= the other blocks of pass P: strip j of the blocks P + 3 .. goes back to HBM, strip j of block P + 2 stays
-#pragma unroll 1
-    for (int blk = NBLK - 1; blk >= P + 2; --blk) {
-      if (P > 0) {
-        spin_ge(&storedS[j], P);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      {
+        const int cp = 64 * P + kNB * j;
+        const int r = opaque(lane & 15), g = opaque(lane >> 4);
+        const double alpha = sigma * K.qsT[cp / d][cp / d];
+        double tfrow[kNB], myscl = 0.0;
+#pragma unroll
+        for (int m = 0; m < kNB; ++m) tfrow[m] = 0.0;
+        double* tpp_row = TppS + wv * kNB * kNB + r * kNB;
+        __builtin_amdgcn_s_setprio(3);
+        pivot_sweep<0, DT>(X, tfrow, tpp_row, myscl, alpha, r);
+        __builtin_amdgcn_s_setprio(0);
+        st.mark(3);
+        wait_slot_free(j, base + P);  // every wavefront is done with this slot's panels of the passes before
+        st.mark(4);
+        double* Vp = Vx + j * kNB * LDV;
+#pragma unroll
+        for (int T4 = 0; T4 < DT / 4; ++T4)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) Vp[r * LDV + 64 * T4 + 16 * g + e] = X[16 * T4 + e];
+        if (g == 0) {
+          sclS[j * kNB + r] = myscl;
+#pragma unroll
+          for (int m = 0; m < kNB; ++m) TfS[j * kNB * kNB + r * kNB + m] = tfrow[m];
+        }
+        lds_done();
+        if (lane == 0) *(volatile lds_int*)&pubS[j] = base + P + 1;
+        {
+          // diagonal block of T: lane (r, g) writes columns 4g .. 4g+3 of row r (zeros above the diagonal)
+          double o4[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) o4[q] = tpp_row[4 * g + q];
+          const int row = cp + r;
+          const bool direct = is_direct(P);
+          const double osc = direct ? pS[row / d] : 1.0;
+#pragma unroll
+          for (int q = 0; q < 4; q += 2) {
+            const double2 t2{osc * o4[q], osc * o4[q + 1]};
+            double* dstp = direct ? Ldst + tiled_index<DT>(row, cp + 4 * g + q) : T + size_t(row) * D + cp + 4 * g + q;
+            *reinterpret_cast<double2*>(dstp) = t2;  // (4 g + q is even: the pair is contiguous in both layouts)
+          }
+        }
+        st.mark(5);
       }
-      load_strip(4 * blk + j, P == 0);
-      st.mark(0);
+      if (!has_trailing) {
 #pragma unroll 1
-      for (int k = 0; k < 4; ++k) {
-        apply_panel(P, k, 4 * blk + j);
-        if (blk == P + 2) bump(&freeS[k]);
+        for (int k = j; k < 4; ++k) mark_done(k, base + P + 1);  // (slots I do not read in this pass)
       }
-      if (blk != P + 2) store_strip(4 * blk + j);
-      st.mark(6);
-    }
-    if (NBLK - 1 >= P + 3) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // my stores have left before the flag moves
-      if (lane == 0) *(volatile lds_int*)&storedS[j] = P + 1;
-    }
-    // ================= the panels of pass P + 1 (the other group's chain) on strip j of block P + 2, my next panel
-    if (has_trailing) {
+      // ================= the other blocks of pass P: strip j of the blocks P + 3 .. goes back to HBM, strip j of block P + 2 stays
 #pragma unroll 1
-      for (int k = 0; k < 4; ++k) {
-        apply_panel(P + 1, k, 4 * (P + 2) + j);
-        bump(&freeS[k]);
+      for (int blk = NBLK - 1; blk >= P + 2; --blk) {
+        if (P > 0) {
+          spin_ge(&storedS[j], base + P);
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        load_strip(4 * blk + j, P == 0);
+        st.mark(0);
+#pragma unroll 1
+        for (int k = 0; k < 4; ++k) {
+          apply_panel(P, k, 4 * blk + j);
+          if (blk == P + 2) mark_done(k, base + P + 1);
+        }
+        if (blk != P + 2) store_strip(4 * blk + j);
+        st.mark(6);
+      }
+      if (NBLK - 1 >= P + 3) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // my stores have left before the flag moves
+        if (lane == 0) *(volatile lds_int*)&storedS[j] = base + P + 1;
+      }
+      // ================= the panels of pass P + 1 (the other group's chain) on strip j of block P + 2, my next panel
+      if (has_trailing) {
+#pragma unroll 1
+        for (int k = 0; k < 4; ++k) {
+          apply_panel(P + 1, k, 4 * (P + 2) + j);
+          mark_done(k, base + P + 2);
+        }
       }
     }
-  }
+    // the group that has no role in the last pass (its panels are applied inside the panel group only) signs off for it
+    if (gi == (NBLK & 1)) {
+#pragma unroll 1
+      for (int k = 0; k < 4; ++k) mark_done(k, base + NBLK);
+    }
+    ++it;
 #ifdef PNODE_TIMING_BUILD
-  if (lane == 0) {
-    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(v.S + size_t(b) * d * d) + wv * 8;
-    for (int i = 0; i < 8; ++i) dbg[i] = st.acc[i];
-  }
+    if (lane == 0) {
+      unsigned long long* dbg = reinterpret_cast<unsigned long long*>(v.S + size_t(b) * d * d) + wv * 8;
+      for (int i = 0; i < 8; ++i) dbg[i] = st.acc[i];
+    }
 #endif
-  if (*abort_word) {
-    // a wait ran into its limit: make the failure visible in every output of the step
-    for (int i = lane; i < D * D; i += 64) {
-      T[i] = __builtin_nan("");
-      Ldst[i] = __builtin_nan("");
+    if (*abort_word) {
+      // a wait ran into its limit: make the failure visible in every output of the step
+      for (int i = lane; i < D * D; i += 64) {
+        T[i] = __builtin_nan("");
+        Ldst[i] = __builtin_nan("");
+      }
     }
   }
 }
@@ -326,10 +386,19 @@ bool dense_lq4_supported(const DenseView& v) {
 }
 
 void dense_launch_lq4(const DenseView& v, const StepArg* args, const IwpConst* K, hipStream_t s) {
+  // one persistent workgroup per CU (a workgroup needs a CU's LDS to itself), each taking every gridDim.x-th trajectory
+  static int cus[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  int& ncu = cus[dev & 63];
+  if (ncu == 0) {
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+  }
+  const dim3 grid(v.B < ncu ? v.B : ncu);
   switch (v.D / 16) {
-    case 8: hipLaunchKernelGGL((dense_lq4_mfma_kernel<8, 2>), dim3(v.B), dim3(512), 0, s, v, args, K); break;
-    case 12: hipLaunchKernelGGL((dense_lq4_mfma_kernel<12, 2>), dim3(v.B), dim3(512), 0, s, v, args, K); break;
-    case 16: hipLaunchKernelGGL((dense_lq4_mfma_kernel<16, 4>), dim3(v.B), dim3(512), 0, s, v, args, K); break;
+    case 8: hipLaunchKernelGGL((dense_lq4_mfma_kernel<8, 2>), grid, dim3(512), 0, s, v, args, K); break;
+    case 12: hipLaunchKernelGGL((dense_lq4_mfma_kernel<12, 2>), grid, dim3(512), 0, s, v, args, K); break;
+    case 16: hipLaunchKernelGGL((dense_lq4_mfma_kernel<16, 4>), grid, dim3(512), 0, s, v, args, K); break;
     default: break;
   }
 }
