@@ -604,7 +604,6 @@ __global__ __launch_bounds__(256, 2) void dense_gain_mfma_kernel(DenseView v, co
   double* Fl = gbuf;            // [d][LDF]     life 2
   double* Sm = gbuf;            // [d][LD]      life 3
   double* wz = gbuf + 2 * d * LD;      // [d]   (beyond all three)
-  double* invd = wz + d;               // [d]
   const int b = blockIdx.x;
   const StepArg arg = args[b];
   if (!arg.active) return;
@@ -703,40 +702,61 @@ __global__ __launch_bounds__(256, 2) void dense_gain_mfma_kernel(DenseView v, co
   __threadfence_block();
   __syncthreads();
   lds_cholesky_blocked<DD, LD>(Sm, tid);
-  if (tid < d) invd[tid] = 1.0 / Sm[tid * LD + tid];
-  __syncthreads();
-  // one thread per column of F (and one for z): register-resident forward substitution
-  if (tid <= W2) {
-    double col[d];
-    if (tid < W2) {
+  // ---- W = C^-1 F as a blocked triangular solve on the matrix core (it was one thread per column: 2 d^2 LDS reads per thread,
+  // bound by the LDS issue rate). (a) inverses of the 16 x 16 diagonal blocks of C, one thread per column of a block;
+  // (b) w = C^-1 z by one wavefront; (c) every wavefront owns whole 16-column tiles of F: for the block rows i = 0 .. DD-1
+  //     R_i = F_i - sum_{j<i} C_ij W_j,  W_i = C_ii^-1 R_i
+  // with the tiles W_j in registers: the C/D fragment of a tile (lane (r, g), register s: row g + 4 s, column r) IS the B
+  // operand of the next product's k-chunk s, so no tile goes through LDS.
+  double* Dinv = gbuf + d * LD;  // [DD][16][17]   (the J/T staging area of life 1 is free now)
+  constexpr int LDI = kNB + 1;
+  if (tid < d) {
+    const int blk = tid / kNB, c = tid % kNB, o = kNB * blk;
+    double x[kNB];
 #pragma unroll
-      for (int a = 0; a < d; ++a) col[a] = F[a * W2 + tid];
-    } else {
+    for (int a2 = 0; a2 < kNB; ++a2) x[a2] = (a2 == c) ? 1.0 : 0.0;
 #pragma unroll
-      for (int a = 0; a < d; ++a) col[a] = wz[a];
+    for (int a2 = 0; a2 < kNB; ++a2) {
+      double acc = x[a2];
+#pragma unroll
+      for (int m = 0; m < a2; ++m) acc -= Sm[(o + a2) * LD + o + m] * x[m];
+      x[a2] = acc / Sm[(o + a2) * LD + o + a2];
     }
 #pragma unroll
-    for (int a = 0; a < d; ++a) {
-      const double w = col[a] * invd[a];
-      col[a] = w;
-#pragma unroll
-      for (int a2 = a + 1; a2 < d; ++a2) col[a2] = fma(-Sm[a2 * LD + a], w, col[a2]);
-    }
-    if (tid < W2) {
-#pragma unroll
-      for (int a = 0; a < d; ++a) F[a * W2 + tid] = col[a];
-    }
-    if (tid == W2) {
-#pragma unroll
-      for (int a = 0; a < d; ++a) wz[a] = col[a];
-    }
+    for (int a2 = 0; a2 < kNB; ++a2) Dinv[(blk * kNB + a2) * LDI + c] = x[a2];  // column c of C_blk^-1
   }
-  __syncthreads();  // W (global, this workgroup) and the solved wz are visible
-  if (tid < W2) {
-    double acc = 0.0;
-#pragma unroll 16
-    for (int a = 0; a < d; ++a) acc += F[a * W2 + tid] * wz[a];
-    v.X[size_t(b) * D * d + tid] = acc;  // tv lives at the head of the X scratch
+  lds_forward_vec_wave<d, LD>(Sm, wz, tid);  // (ends with a workgroup barrier: Dinv and wz are visible)
+  constexpr int NCT = W2 / kNB;  // column tiles of F
+  for (int ct = wv; ct < NCT; ct += 4) {
+    double4_t w[DD];
+#pragma unroll
+    for (int i = 0; i < DD; ++i) {
+      double4_t acc;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = F[(kNB * i + g + 4 * q) * W2 + kNB * ct + r];
+#pragma unroll
+      for (int jb = 0; jb < DD; ++jb) {
+        if (jb < i) {
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) acc = MFMA64(-Sm[(kNB * i + r) * LD + kNB * jb + 4 * s4 + g], w[jb][s4], acc);
+        }
+      }
+      double4_t wi = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) wi = MFMA64(Dinv[(i * kNB + r) * LDI + 4 * s4 + g], acc[s4], wi);
+      w[i] = wi;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) F[(kNB * i + g + 4 * q) * W2 + kNB * ct + r] = wi[q];
+    }
+    // tv = W^T (C^-1 z) for my 16 columns: lane (r, g) holds the rows g + 4 q of every block row of column r
+    double part = 0.0;
+#pragma unroll
+    for (int i = 0; i < DD; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) part = fma(w[i][q], wz[kNB * i + g + 4 * q], part);
+    part += __shfl_xor(part, 16, kWave);
+    part += __shfl_xor(part, 32, kWave);
+    if (g == 0) v.X[size_t(b) * D * d + kNB * ct + r] = part;  // tv lives at the head of the X scratch
   }
 }
 
