@@ -278,7 +278,9 @@ __global__ __launch_bounds__(512) void dense_lq4_mfma_kernel(const DenseView v, 
       for (int kk = 0; kk < 3; ++kk) {
         if (kk < j) {
           apply_panel(P, kk, mystrip);
-          if (!has_trailing) mark_done(kk, base + P + 1);
+          // (no further role in this trajectory after a pass without trailing blocks: sign off for ALL its remaining passes, so
+          // that wavefront 0 of this group may publish into the slot for the NEXT trajectory as soon as the other group is done)
+          if (!has_trailing) mark_done(kk, base + NBLK);
         }
       }
       {
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(512) void dense_lq4_mfma_kernel(const DenseView v, 
       }
       if (!has_trailing) {
 #pragma unroll 1
-        for (int k = j; k < 4; ++k) mark_done(k, base + P + 1);  // (slots I do not read in this pass)
+        for (int k = j; k < 4; ++k) mark_done(k, base + NBLK);  // (slots I do not read in this pass, nor later in this trajectory)
       }
       // ================= the other blocks of pass P: strip j of the blocks P + 3 .. goes back to HBM, strip j of block P + 2 stays
 #pragma unroll 1
