@@ -72,6 +72,7 @@ __global__ __launch_bounds__(512) void dense_lq4_mfma_kernel(const DenseView v, 
   __shared__ int pubS[4], storedS[4];
   __shared__ int doneS[4 * 8];  // doneS[8 k + w] = G: wavefront w will not read the content of slot k of any global pass < G again
   __shared__ int prepS;  // number of trajectories whose coefS / pSS are written
+  __shared__ int trajS[8];  // trajS[w]: trajectories wavefront w has finished
   __shared__ int abortS;
 
   // PERSISTENT workgroups: the grid is one workgroup per CU (at most), each walks over the trajectories b = blockIdx.x,
@@ -86,6 +87,7 @@ __global__ __launch_bounds__(512) void dense_lq4_mfma_kernel(const DenseView v, 
   if (tid == 0) {
     for (int k = 0; k < 4; ++k) pubS[k] = storedS[k] = 0;
     for (int k = 0; k < 32; ++k) doneS[k] = 0;
+    for (int k = 0; k < 8; ++k) trajS[k] = 0;
     prepS = 0;
     abortS = 0;
   }
@@ -239,8 +241,22 @@ __global__ __launch_bounds__(512) void dense_lq4_mfma_kernel(const DenseView v, 
     coef = coefS[it & 1];
     pS = pSS[it & 1];
     if (wv == 0) {
-      // Mt = (Abar P^-1 (x) I) L is formed while the strips are read: coef[i][k] = Abar[i][k] / p_k. (Group A is at most one
-      // trajectory ahead of group B: the slot of the trajectory before last is free.)
+      // Mt = (Abar P^-1 (x) I) L is formed while the strips are read: coef[i][k] = Abar[i][k] / p_k. The tables of trajectory
+      // it - 2 are overwritten: wait until every wavefront has finished that trajectory (wavefront 0 runs ahead of the others:
+      // at D = 128 it is done with a trajectory after ONE sweep, while the last pass still scales its output with pS).
+      if (it >= 2) {
+        int n = 0;
+        while (true) {
+          const int mine = (lane < 8) ? *(volatile lds_int*)&trajS[lane] : 0x7fffffff;
+          if (!__any(mine < it - 1)) break;
+          __builtin_amdgcn_s_sleep(4);
+          if ((++n & 255) == 0 && (n > kSpinLimit || __builtin_amdgcn_readfirstlane(*abort_word))) {
+            *abort_word = 1;
+            break;
+          }
+        }
+        asm volatile("" ::: "memory");
+      }
       if (lane == 0) {
         double pl[kMaxN], pil[kMaxN];
         precond_rt(nn, sarg.dt, K, pl, pil);
@@ -366,6 +382,8 @@ __global__ __launch_bounds__(512) void dense_lq4_mfma_kernel(const DenseView v, 
       for (int k = 0; k < 4; ++k) mark_done(k, base + NBLK);
     }
     ++it;
+    lds_done();
+    if (lane == 0) *(volatile lds_int*)&trajS[wv] = it;
 #ifdef PNODE_TIMING_BUILD
     if (lane == 0) {
       unsigned long long* dbg = reinterpret_cast<unsigned long long*>(v.S + size_t(b) * d * d) + wv * 8;

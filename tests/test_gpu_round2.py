@@ -210,3 +210,54 @@ def test_checkpoint_covariance_factors_of_the_filter(hip_lib, case, monkeypatch)
         cov = R[i - 1].T @ R[i - 1]
         # (Van der Pol: z = m'' - f cancels large terms, the factors carry ~1e-6 of rounding noise after a few dozen steps)
         assert np.max(np.abs(cov - cov_ref)) <= (1e-5 if case == "small_vdp2" else 1e-7) * np.max(np.abs(cov_ref)), (case, i)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,nu", [(16, 3), (16, 5), (32, 3)])
+def test_persistent_workgroups_with_inactive_trajectories_in_their_sequence(hip_lib, N, nu):
+    """The one-launch LQ runs one persistent workgroup per CU; with more trajectories than CUs a workgroup takes several, the passes
+    of consecutive trajectories overlap (group A is in the next trajectory while group B finishes the current one) and inactive
+    trajectories are skipped inside the sequence. 700 trajectories (2-3 per workgroup), random activity masks and random
+    accept/reject decisions over three attempts, at D = 128, 192 (an odd number of 64-row blocks: group A owns two consecutive
+    passes across the trajectory boundary) and 256: every error estimate and every mean must agree with the two-launch kernels
+    (`pnode_set_generic_path(h, 3)`), which know nothing of workgroup sequences."""
+    from probdiffeq_hip import _backend, vector_fields as V
+    from helpers import brusselator_y0, tcoeffs
+
+    rng = np.random.default_rng(7)
+    B = 700
+    vf = V.brusselator(N)
+    y0 = np.stack([brusselator_y0(N, ph) for ph in rng.uniform(0.0, 2.0, B)])
+    tc = np.stack(tcoeffs(vf, [y0], nu), axis=1)
+
+    def make(path):
+        bt = _backend.Batch(batch=B, d=vf.d, nu=nu, ode_order=1, model="dense", correction="ts1", strategy="filter",
+                            calibration="dynamic", vf_id=vf.vf_id, vf_params=vf.param_array(), num_checkpoints=2)
+        if path:
+            bt.set_generic_path(path)
+        bt.set_initial(tc, np.zeros(B), np.ones(B))
+        bt.set_tolerances(1e-5, 1e-5)
+        return bt
+
+    one, two = make(0), make(3)
+    e1, e2 = np.zeros(B), np.zeros(B)
+    for it in range(3):
+        dts = 0.01 * rng.uniform(0.5, 2.0, B)
+        act = (rng.uniform(size=B) < 0.7).astype(np.uint8)
+        acc = (act & (rng.uniform(size=B) < 0.8)).astype(np.uint8)
+        one.attempt_step(dts, act, e1)
+        two.attempt_step(dts, act, e2)
+        live = act.astype(bool)
+        assert np.all(np.isfinite(e1[live]))
+        assert np.max(np.abs(e1[live] - e2[live]) / e2[live]) < 1e-7, it
+        one.commit(acc)
+        two.commit(acc)
+        m1, m2 = one.read_mean(0), two.read_mean(0)
+        assert np.max(np.abs(m1[:, 0] - m2[:, 0])) <= 1e-10 * np.max(np.abs(m2[:, 0])), it
+        assert np.max(np.abs(m1[:, 1] - m2[:, 1])) <= 1e-8 * np.max(np.abs(m2[:, 1])), it
+    R1, R2 = one.read_factor(0), two.read_factor(0)
+    for b in (0, 255, 256, 511, 512, B - 1):
+        c1, c2 = R1[b].T @ R1[b], R2[b].T @ R2[b]
+        assert np.max(np.abs(c1 - c2)) <= 1e-8 * np.max(np.abs(c2)), b
+    one.close()
+    two.close()
