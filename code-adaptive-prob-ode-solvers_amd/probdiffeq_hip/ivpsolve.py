@@ -22,6 +22,9 @@ from . import _backend
 from .ivpsolvers import InitialCondition, Solver
 from .vector_fields import UserVectorField, VectorField
 
+# accepted steps per trajectory that the device-side store of strategy_smoother holds by default (solve_adaptive_save_every_step)
+SMOOTHER_MAX_STEPS = 16384
+
 
 @dataclasses.dataclass(frozen=True)
 class PIControl:
@@ -368,7 +371,7 @@ def _save_every_step_smoother(vector_field, init, t0b, t1b, adaptive_solver, dt0
 
 
 def solve_adaptive_save_every_step(vector_field, initial_condition: InitialCondition, t0, t1,
-                                   adaptive_solver: AdaptiveSolver, dt0, *, device=None, max_steps=16384):
+                                   adaptive_solver: AdaptiveSolver, dt0, *, device=None, max_steps=None):
     """Adaptive solve that returns every accepted step (vdp.py:77-79). Ragged over the batch: returns a
     Solution for an unbatched initial condition and a list of Solutions otherwise. Meant for small
     problems: each accepted batched step copies the means back to the host (strategy_filter) or stores the step with its
@@ -378,7 +381,7 @@ def solve_adaptive_save_every_step(vector_field, initial_condition: InitialCondi
         B0 = initial_condition.tcoeffs.shape[0]
         return _save_every_step_smoother(vector_field, initial_condition, np.array(np.broadcast_to(t0, (B0,)), dtype=np.float64),
                                          np.array(np.broadcast_to(t1, (B0,)), dtype=np.float64), adaptive_solver, dt0, device,
-                                         int(max_steps))
+                                         int(SMOOTHER_MAX_STEPS if max_steps is None else max_steps))
     if solver.strategy.kind != "filter":
         raise NotImplementedError("solve_adaptive_save_every_step is implemented for strategy_filter (vdp.py:65) and "
                                   "strategy_smoother (ivpsolvers.py:112); use solve_adaptive_save_at with fixedpoint")

@@ -6,8 +6,12 @@ dt0 0.01, 200 checkpoints. Writes the same result-dict schema as the reference
 ({"N", "runtime", "memory", "ts", "ys", "num_steps"}; run.py:23-38,142-151) to
 experiments/data_checkpoint.npy and prints, per N, the accepted-step count next to the reference's committed
 one (tests/golden/brusselator.npz) and the run time next to the reference's (JAX/CPU, compile time included).
+The "textbook" half of the experiment (run.py:82-116: terminal-value solve for the step count and the memory a
+store-every-step smoother would need, then that smoother itself while it fits) goes to experiments/data_textbook.npy
+with the reference's keys; the smoother runs while the steps fit the device-side store (ivpsolve.SMOOTHER_MAX_STEPS)
+and the reference's own 4000 MB gate.
 
-  python experiments/brusselator_checkpoints.py [--max-n 512] [--controller host|device] [--nosave]
+  python experiments/brusselator_checkpoints.py [--max-n 512] [--controller host|device] [--nosave] [--outdir DIR]
 """
 import argparse
 import os
@@ -25,14 +29,16 @@ from probdiffeq_hip import ivpsolve, ivpsolvers, taylor  # noqa: E402
 from probdiffeq_hip.impl import impl  # noqa: E402
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--max-n", type=int, default=512)
     ap.add_argument("--controller", default="device", choices=["host", "device"])
     ap.add_argument("--nosave", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--outdir", default=os.path.dirname(os.path.abspath(__file__)))
+    args = ap.parse_args(argv)
     golden = np.load(os.path.join(ROOT, "tests", "golden", "brusselator.npz"))
     results = {"N": [], "runtime": [], "memory": [], "ts": [], "ys": [], "num_steps": []}
+    textbook = {"N": [], "runtime": [], "memory": [], "ts": [], "ys": [], "num_steps": []}
     print(f"{'N':>5s} {'steps':>9s} {'reference':>9s} {'runtime s':>10s} {'ref runtime s':>13s} {'max |ys - ref|':>15s}")
     for i, N in enumerate(int(n) for n in golden["N"]):
         if N > args.max_n:
@@ -52,6 +58,21 @@ def main():
         init = solver.initial_condition(tcoeffs, 1.0)
         save_at = np.linspace(t0, t1, num=200)
         size_init = 3 * 8 * ((num + 1) * 2 * N + 3 * (num + 1) ** 2 + (num + 1) * 2 * N)  # three state copies (run.py:68-70)
+        # ---- textbook half (run.py:82-116)
+        terminal = ivpsolve.solve_adaptive_terminal_values(vf, init, t0=t0, t1=t1, dt0=0.01, adaptive_solver=adaptive_solver)
+        nsteps_terminal = int(np.amax(terminal.num_steps))
+        total_memory = nsteps_terminal * size_init / 1024**2
+        textbook["N"].append(N)
+        textbook["memory"].append(total_memory)
+        textbook["num_steps"].append(nsteps_terminal)
+        if total_memory < 4000 and nsteps_terminal < ivpsolve.SMOOTHER_MAX_STEPS:
+            solver_ = ivpsolvers.solver_dynamic(ivpsolvers.strategy_smoother(ibm, ts0))
+            adaptive_solver_ = ivpsolve.adaptive(solver_, atol=tol, rtol=tol, control=ctrl)
+            count0 = time.perf_counter()
+            ivpsolve.solve_adaptive_save_every_step(vf, solver_.initial_condition(tcoeffs, 1.0), t0=t0, t1=t1, dt0=0.01,
+                                                    adaptive_solver=adaptive_solver_)
+            textbook["runtime"].append(time.perf_counter() - count0)
+        # ---- checkpoint half (run.py:118-138)
         count0 = time.perf_counter()
         solution = ivpsolve.solve_adaptive_save_at(vf, init, save_at=save_at, dt0=0.01, adaptive_solver=adaptive_solver,
                                                    device_controller=args.controller == "device")
@@ -68,7 +89,8 @@ def main():
         print(f"{N:5d} {steps:9d} {int(golden['num_steps_checkpoint'][i]):9d} {count1:10.3f} {golden['runtime_checkpoint'][i]:13.3f} {dev}",
               flush=True)
     if not args.nosave:
-        np.save(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data_checkpoint.npy"), results, allow_pickle=True)
+        np.save(os.path.join(args.outdir, "data_checkpoint.npy"), results, allow_pickle=True)
+        np.save(os.path.join(args.outdir, "data_textbook.npy"), textbook, allow_pickle=True)
 
 
 if __name__ == "__main__":

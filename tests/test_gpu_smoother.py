@@ -163,3 +163,33 @@ def test_workprecision_result_files_have_the_reference_schema(hip_lib, golden, t
     ts, ys = np.load(tmp_path / "data_ts.npy"), np.load(tmp_path / "data_ys.npy")
     assert ys.shape == (len(ts), 3) and ts[0] == 0.0 and ts[-1] == 50.0
     assert any("one batch" in k for k in res)
+
+
+def test_experiment4_result_files_have_the_reference_schema(hip_lib, golden, tmp_path):
+    """SURVEY 8(f)-4, second script: experiments/brusselator_checkpoints.py writes the two dicts of the reference's experiment 4
+    (/root/reference/experiments/4_brusselator/run.py:23-38, 142-151): `data_checkpoint.npy` and `data_textbook.npy`, keys
+    N / runtime / memory / ts / ys / num_steps. N = 2 .. 16 here: the step counts of both halves are the reference's committed
+    ones (N = 2 is the equilibrium, N = 8 a rounding-sensitive decision: excluded as in test_oracle_golden.py), the store-every-step
+    smoother ran wherever the reference's memory gate lets it."""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("brusselator_checkpoints", os.path.join(root, "experiments", "brusselator_checkpoints.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.main(["--max-n", "16", "--outdir", str(tmp_path)])
+    ck = np.load(tmp_path / "data_checkpoint.npy", allow_pickle=True).item()
+    tb = np.load(tmp_path / "data_textbook.npy", allow_pickle=True).item()
+    keys = {"N", "runtime", "memory", "ts", "ys", "num_steps"}
+    assert set(ck.keys()) == keys and set(tb.keys()) == keys
+    g = golden["brusselator"]
+    assert ck["N"] == [2, 4, 8, 16] and tb["N"] == [2, 4, 8, 16]
+    for i, N in enumerate(ck["N"]):
+        assert ck["ts"][i].shape == (200,) and ck["ys"][i].shape == (200, 2 * N)
+        if N in (4, 16):
+            assert ck["num_steps"][i] == int(g["num_steps_checkpoint"][i])
+            assert tb["num_steps"][i] == int(g["num_steps_terminal"][i])
+        assert abs(ck["memory"][i] - float(g["memory_checkpoint_mb"][i])) <= 0.02 * float(g["memory_checkpoint_mb"][i])
+    assert len(tb["runtime"]) == 4 and all(r > 0 for r in tb["runtime"])  # every N here passes the 4000 MB gate
+    assert tb["ts"] == [] and tb["ys"] == []  # (the reference never fills them either)
