@@ -590,9 +590,121 @@ __global__ __launch_bounds__(256) void dense_begin_mfma_kernel(DenseView v, cons
   if (tid == 0) v.sig_new[b] = v.dynamic ? sigma_hat : v.sigma[size_t(arg.src) * sB + b];
 }
 
-// Gain kernel: F = H L^-, S = F F^T = C C^T, W = C^-1 F (to global v.Ft), tv = W^T C^-1 z (to v.X).
+// Strip update: Y^T = W X^T, X^T -= W^T Y^T on the first 2d columns, copy of the rest, mean update,
+// and (block 0: rows of the zeroth derivative) the normalised error norm.
+// Second half of the measurement-update kernel (it was a kernel of its own, with W and tv handed over through global memory):
+// W (d x 2d, row stride LDF) and tv = W^T C^-1 z are in LDS when it is entered, all wavefronts past a barrier.
 template <int DT, int DD>
-__global__ __launch_bounds__(256, 2) void dense_gain_mfma_kernel(DenseView v, const StepArg* __restrict__ args,
+__device__ __forceinline__ void strip_update_body(const DenseView& v, const StepArg& arg, const IwpConst& K, int b,
+                                                  const double* __restrict__ Fw, const double* __restrict__ tv, double* red) {
+  constexpr int D = 16 * DT, d = 16 * DD, W2 = 2 * d, LDF = W2 + 1;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const double* __restrict__ T = v.R + size_t(b) * D * D;
+  const size_t sB = size_t(v.B);
+  double* mdst = v.mean + (size_t(arg.dst) * sB + b) * D;
+  double* __restrict__ Ln = v.U + (size_t(arg.dst) * sB + b) * D * D;
+  // one workgroup per trajectory walks all strip groups: W (64 KB) is staged once instead of once per group
+  for (int st = wv; st < DT; st += 4) {
+    const int row = 16 * st + r;
+    const int iblk = (16 * st) / d;
+    double pr;
+    {
+      double p[kMaxN], pinv[kMaxN];
+      precond_rt(v.n, arg.dt, K, p, pinv);
+      pr = p[0];
+#pragma unroll
+      for (int i = 1; i < kMaxN; ++i) pr = (i == iblk) ? p[i] : pr;
+    }
+    // register strip in the HBM layout  X[16 T + 4 j + q] = p_r T[row][64 T + 16 g + 4 j + q]  (128 B per lane
+    // and super-tile); T's upper triangle is stored as zeros, so no predicate is needed
+    double X[W2 / 4];
+    double mpart = 0.0;
+    const double* __restrict__ trow = T + size_t(row) * D + 16 * g;
+#pragma unroll
+    for (int T4 = 0; T4 < W2 / 64; ++T4)
+#pragma unroll
+      for (int e = 0; e < 16; e += 2) {
+        const double2 t2 = *reinterpret_cast<const double2*>(trow + 64 * T4 + e);
+        X[16 * T4 + e] = pr * t2.x;
+        X[16 * T4 + e + 1] = pr * t2.y;
+      }
+#pragma unroll
+    for (int T4 = 0; T4 < W2 / 64; ++T4)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mpart = fma(X[16 * T4 + e], tv[64 * T4 + 16 * g + e], mpart);
+    mpart += __shfl_xor(mpart, 16, kWave);
+    mpart += __shfl_xor(mpart, 32, kWave);
+    if (g == 0) mdst[row] -= mpart;
+    double4_t yT[DD];
+#pragma unroll
+    for (int ta = 0; ta < DD; ++ta) {
+      double4_t a0 = {0.0, 0.0, 0.0, 0.0}, a1 = a0;
+#pragma unroll
+      for (int T4 = 0; T4 < W2 / 64; ++T4)
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+          const double* wrow = Fw + (16 * ta + r) * LDF + 64 * T4 + 16 * g + e;
+          a0 = MFMA64(wrow[0], X[16 * T4 + e], a0);
+          a1 = MFMA64(wrow[1], X[16 * T4 + e + 1], a1);
+        }
+      yT[ta] = a0 + a1;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const int coff = 16 * (r & 3) + (r >> 2);
+#pragma unroll
+    for (int T4 = 0; T4 < W2 / 64; ++T4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        double4_t c4 = {X[16 * T4 + 4 * j], X[16 * T4 + 4 * j + 1], X[16 * T4 + 4 * j + 2], X[16 * T4 + 4 * j + 3]};
+#pragma unroll
+        for (int kk = 0; kk < d / 4; ++kk)
+          c4 = MFMA64(-Fw[(4 * kk + g) * LDF + 64 * T4 + 4 * j + coff], yT[kk >> 2][kk & 3], c4);
+        X[16 * T4 + 4 * j] = c4[0];
+        X[16 * T4 + 4 * j + 1] = c4[1];
+        X[16 * T4 + 4 * j + 2] = c4[2];
+        X[16 * T4 + 4 * j + 3] = c4[3];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    {
+      // the state factor is stored in the register order of the strips (pnode_mfma_common.hpp): 1 KB per store instruction
+      double2* __restrict__ lrow = reinterpret_cast<double2*>(Ln) + size_t(st) * (2 * DT) * 64 + lane;
+#pragma unroll
+      for (int T4 = 0; T4 < W2 / 64; ++T4)
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+          double2 t2;
+          t2.x = X[16 * T4 + e];
+          t2.y = X[16 * T4 + e + 1];
+          lrow[(8 * T4 + e / 2) * 64] = t2;
+        }
+    }
+    // (columns >= 2d of these rows were written by the LQ kernel, already scaled)
+  }
+  {
+    // error norm over u = m[0] (rows 0 .. d-1 were updated above)
+    __syncthreads();
+    const double atol = v.atol[b], rtol = v.rtol[b];
+    double part = 0.0;
+    for (int j = tid; j < d; j += 256) {
+      const double rel = v.err[size_t(b) * d + j] / (atol + rtol * fabs(mdst[j]));
+      part += rel * rel;
+    }
+    part = wave_sum(part);
+    if (lane == 0) red[wv] = part;
+    __syncthreads();
+    if (tid == 0) {
+      v.errnorm[b] = sqrt((red[0] + red[1] + red[2] + red[3]) / double(d));
+      v.sigma[size_t(arg.dst) * sB + b] = v.sig_new[b];
+    }
+  }
+}
+
+// Measurement update, ONE kernel per trajectory: F = H L^-, S = F F^T = C C^T, W = C^-1 F, tv = W^T C^-1 z, then (strip_update_body)
+// L = L^- - (L^- W^T) W on the first 2d columns, the mean and the error norm. W and tv stay on chip (registers -> LDS).
+template <int DT, int DD>
+__global__ __launch_bounds__(256, 2) void dense_correct_mfma_kernel(DenseView v, const StepArg* __restrict__ args,
                                                               const IwpConst* __restrict__ Kc) {
   constexpr int D = 16 * DT, d = 16 * DD, W2 = 2 * d, LD = d + 1, LDF = W2 + 1;
   // One LDS buffer, three lives: (1) J and T[0:d, 0:d] staged for the MFMA that forms F (both were MFMA operands read
@@ -604,6 +716,8 @@ __global__ __launch_bounds__(256, 2) void dense_gain_mfma_kernel(DenseView v, co
   double* Fl = gbuf;            // [d][LDF]     life 2
   double* Sm = gbuf;            // [d][LD]      life 3
   double* wz = gbuf + 2 * d * LD;      // [d]   (beyond all three)
+  double* tvs = wz + d;                // [2d]  tv = W^T C^-1 z
+  double* red = tvs + W2;              // [4]
   const int b = blockIdx.x;
   const StepArg arg = args[b];
   if (!arg.active) return;
@@ -727,169 +841,54 @@ __global__ __launch_bounds__(256, 2) void dense_gain_mfma_kernel(DenseView v, co
   }
   lds_forward_vec_wave<d, LD>(Sm, wz, tid);  // (ends with a workgroup barrier: Dinv and wz are visible)
   constexpr int NCT = W2 / kNB;  // column tiles of F
-  for (int ct = wv; ct < NCT; ct += 4) {
-    double4_t w[DD];
+  constexpr int NMY = (NCT + 3) / 4;  // per wavefront
+  double4_t w[NMY][DD];
 #pragma unroll
-    for (int i = 0; i < DD; ++i) {
-      double4_t acc;
+  for (int tt = 0; tt < NMY; ++tt) {
+    const int ct = wv + 4 * tt;
+    if (ct < NCT) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) acc[q] = F[(kNB * i + g + 4 * q) * W2 + kNB * ct + r];
+      for (int i = 0; i < DD; ++i) {
+        double4_t acc;
 #pragma unroll
-      for (int jb = 0; jb < DD; ++jb) {
-        if (jb < i) {
+        for (int q = 0; q < 4; ++q) acc[q] = F[(kNB * i + g + 4 * q) * W2 + kNB * ct + r];
 #pragma unroll
-          for (int s4 = 0; s4 < 4; ++s4) acc = MFMA64(-Sm[(kNB * i + r) * LD + kNB * jb + 4 * s4 + g], w[jb][s4], acc);
+        for (int jb = 0; jb < DD; ++jb) {
+          if (jb < i) {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) acc = MFMA64(-Sm[(kNB * i + r) * LD + kNB * jb + 4 * s4 + g], w[tt][jb][s4], acc);
+          }
         }
+        double4_t wi = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) wi = MFMA64(Dinv[(i * kNB + r) * LDI + 4 * s4 + g], acc[s4], wi);
+        w[tt][i] = wi;
       }
-      double4_t wi = {0.0, 0.0, 0.0, 0.0};
+      // tv = W^T (C^-1 z) for my 16 columns: lane (r, g) holds the rows g + 4 q of every block row of column r
+      double part = 0.0;
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) wi = MFMA64(Dinv[(i * kNB + r) * LDI + 4 * s4 + g], acc[s4], wi);
-      w[i] = wi;
+      for (int i = 0; i < DD; ++i)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) F[(kNB * i + g + 4 * q) * W2 + kNB * ct + r] = wi[q];
-    }
-    // tv = W^T (C^-1 z) for my 16 columns: lane (r, g) holds the rows g + 4 q of every block row of column r
-    double part = 0.0;
-#pragma unroll
-    for (int i = 0; i < DD; ++i)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) part = fma(w[i][q], wz[kNB * i + g + 4 * q], part);
-    part += __shfl_xor(part, 16, kWave);
-    part += __shfl_xor(part, 32, kWave);
-    if (g == 0) v.X[size_t(b) * D * d + kNB * ct + r] = part;  // tv lives at the head of the X scratch
-  }
-}
-
-// Strip update: Y^T = W X^T, X^T -= W^T Y^T on the first 2d columns, copy of the rest, mean update,
-// and (block 0: rows of the zeroth derivative) the normalised error norm.
-template <int DT, int DD>
-__global__ __launch_bounds__(256, 2) void dense_strip_update_mfma_kernel(DenseView v, const StepArg* __restrict__ args,
-                                                                         const IwpConst* __restrict__ Kc) {
-  constexpr int D = 16 * DT, d = 16 * DD, W2 = 2 * d, LDF = W2 + 1;
-  extern __shared__ double smem[];
-  double* Fw = smem;          // [d][LDF]
-  double* tv = Fw + d * LDF;  // [W2]
-  double* red = tv + W2;      // [4]
-  const int b = blockIdx.y;
-  const StepArg arg = args[b];
-  if (!arg.active) return;
-  const IwpConst& K = *Kc;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int r = lane & 15, g = lane >> 4;
-  const double* __restrict__ T = v.R + size_t(b) * D * D;
-  const double* __restrict__ Wg = v.Ft + size_t(b) * d * D;
-  {
-    constexpr int NL = d * W2 / 512;  // double2 loads per thread
-    double2 tmp[NL];
-#pragma unroll
-    for (int e = 0; e < NL; ++e) tmp[e] = reinterpret_cast<const double2*>(Wg)[tid + 256 * e];
-#pragma unroll
-    for (int e = 0; e < NL; ++e) {
-      const int idx = 2 * (tid + 256 * e);
-      Fw[(idx / W2) * LDF + idx % W2] = tmp[e].x;
-      Fw[(idx / W2) * LDF + idx % W2 + 1] = tmp[e].y;
+        for (int q = 0; q < 4; ++q) part = fma(w[tt][i][q], wz[kNB * i + g + 4 * q], part);
+      part += __shfl_xor(part, 16, kWave);
+      part += __shfl_xor(part, 32, kWave);
+      if (g == 0) tvs[kNB * ct + r] = part;
     }
   }
-  for (int c = tid; c < W2; c += 256) tv[c] = v.X[size_t(b) * D * d + c];
+  __syncthreads();  // every wavefront is done with C and the inverse diagonal blocks: W takes their place in LDS
+  double* Fw = gbuf;  // [d][LDF]   life 4
+#pragma unroll
+  for (int tt = 0; tt < NMY; ++tt) {
+    const int ct = wv + 4 * tt;
+    if (ct < NCT) {
+#pragma unroll
+      for (int i = 0; i < DD; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Fw[(kNB * i + g + 4 * q) * LDF + kNB * ct + r] = w[tt][i][q];
+    }
+  }
   __syncthreads();
-  const size_t sB = size_t(v.B);
-  double* mdst = v.mean + (size_t(arg.dst) * sB + b) * D;
-  double* __restrict__ Ln = v.U + (size_t(arg.dst) * sB + b) * D * D;
-  // one workgroup per trajectory walks all strip groups: W (64 KB) is staged once instead of once per group
-  for (int st = wv; st < DT; st += 4) {
-    const int row = 16 * st + r;
-    const int iblk = (16 * st) / d;
-    double pr;
-    {
-      double p[kMaxN], pinv[kMaxN];
-      precond_rt(v.n, arg.dt, K, p, pinv);
-      pr = p[0];
-#pragma unroll
-      for (int i = 1; i < kMaxN; ++i) pr = (i == iblk) ? p[i] : pr;
-    }
-    // register strip in the HBM layout  X[16 T + 4 j + q] = p_r T[row][64 T + 16 g + 4 j + q]  (128 B per lane
-    // and super-tile); T's upper triangle is stored as zeros, so no predicate is needed
-    double X[W2 / 4];
-    double mpart = 0.0;
-    const double* __restrict__ trow = T + size_t(row) * D + 16 * g;
-#pragma unroll
-    for (int T4 = 0; T4 < W2 / 64; ++T4)
-#pragma unroll
-      for (int e = 0; e < 16; e += 2) {
-        const double2 t2 = *reinterpret_cast<const double2*>(trow + 64 * T4 + e);
-        X[16 * T4 + e] = pr * t2.x;
-        X[16 * T4 + e + 1] = pr * t2.y;
-      }
-#pragma unroll
-    for (int T4 = 0; T4 < W2 / 64; ++T4)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) mpart = fma(X[16 * T4 + e], tv[64 * T4 + 16 * g + e], mpart);
-    mpart += __shfl_xor(mpart, 16, kWave);
-    mpart += __shfl_xor(mpart, 32, kWave);
-    if (g == 0) mdst[row] -= mpart;
-    double4_t yT[DD];
-#pragma unroll
-    for (int ta = 0; ta < DD; ++ta) {
-      double4_t a0 = {0.0, 0.0, 0.0, 0.0}, a1 = a0;
-#pragma unroll
-      for (int T4 = 0; T4 < W2 / 64; ++T4)
-#pragma unroll
-        for (int e = 0; e < 16; e += 2) {
-          const double* wrow = Fw + (16 * ta + r) * LDF + 64 * T4 + 16 * g + e;
-          a0 = MFMA64(wrow[0], X[16 * T4 + e], a0);
-          a1 = MFMA64(wrow[1], X[16 * T4 + e + 1], a1);
-        }
-      yT[ta] = a0 + a1;
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    const int coff = 16 * (r & 3) + (r >> 2);
-#pragma unroll
-    for (int T4 = 0; T4 < W2 / 64; ++T4) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        double4_t c4 = {X[16 * T4 + 4 * j], X[16 * T4 + 4 * j + 1], X[16 * T4 + 4 * j + 2], X[16 * T4 + 4 * j + 3]};
-#pragma unroll
-        for (int kk = 0; kk < d / 4; ++kk)
-          c4 = MFMA64(-Fw[(4 * kk + g) * LDF + 64 * T4 + 4 * j + coff], yT[kk >> 2][kk & 3], c4);
-        X[16 * T4 + 4 * j] = c4[0];
-        X[16 * T4 + 4 * j + 1] = c4[1];
-        X[16 * T4 + 4 * j + 2] = c4[2];
-        X[16 * T4 + 4 * j + 3] = c4[3];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    {
-      // the state factor is stored in the register order of the strips (pnode_mfma_common.hpp): 1 KB per store instruction
-      double2* __restrict__ lrow = reinterpret_cast<double2*>(Ln) + size_t(st) * (2 * DT) * 64 + lane;
-#pragma unroll
-      for (int T4 = 0; T4 < W2 / 64; ++T4)
-#pragma unroll
-        for (int e = 0; e < 16; e += 2) {
-          double2 t2;
-          t2.x = X[16 * T4 + e];
-          t2.y = X[16 * T4 + e + 1];
-          lrow[(8 * T4 + e / 2) * 64] = t2;
-        }
-    }
-    // (columns >= 2d of these rows were written by the LQ kernel, already scaled)
-  }
-  {
-    // error norm over u = m[0] (rows 0 .. d-1 were updated above)
-    __syncthreads();
-    const double atol = v.atol[b], rtol = v.rtol[b];
-    double part = 0.0;
-    for (int j = tid; j < d; j += 256) {
-      const double rel = v.err[size_t(b) * d + j] / (atol + rtol * fabs(mdst[j]));
-      part += rel * rel;
-    }
-    part = wave_sum(part);
-    if (lane == 0) red[wv] = part;
-    __syncthreads();
-    if (tid == 0) {
-      v.errnorm[b] = sqrt((red[0] + red[1] + red[2] + red[3]) / double(d));
-      v.sigma[size_t(arg.dst) * sB + b] = v.sig_new[b];
-    }
-  }
+  strip_update_body<DT, DD>(v, arg, K, b, Fw, tvs, red);
 }
 
 bool dense_mfma_supported(const DenseView& v) {
@@ -911,26 +910,18 @@ static void launch_mfma(const DenseView& v, const StepArg* args, const IwpConst*
     hipLaunchKernelGGL((dense_lq2_mfma_kernel<DT, false>), dim3(v.B), dim3(256), 0, s, v, args, K, 1);
   }
   mark(3);
-  constexpr int d = 16 * DD, W2 = 2 * d;
+  constexpr int d = 16 * DD;
   static_assert(DD <= 4, "the error norm is computed by strip block 0, which must cover the d rows of u");
-  const size_t shm1 = (size_t(2) * d * (d + 1) + 2 * d) * sizeof(double);  // >= d (2d + 1): see the kernel
+  const size_t shm1 = (size_t(2) * d * (d + 1) + 3 * d + 8) * sizeof(double);  // >= d (2d + 1) + 3d + 4: see the kernel
   int dev = 0;
   (void)hipGetDevice(&dev);
   static bool attr1[64] = {};  // the opt-in to > 64 KB of dynamic LDS is per function AND per device
   if (!attr1[dev & 63]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_gain_mfma_kernel<DT, DD>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_correct_mfma_kernel<DT, DD>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, int(shm1));
     attr1[dev & 63] = true;
   }
-  hipLaunchKernelGGL((dense_gain_mfma_kernel<DT, DD>), dim3(v.B), dim3(256), shm1, s, v, args, K);
-  const size_t shm2 = (size_t(d) * (W2 + 1) + W2 + 4) * sizeof(double);
-  static bool attr2[64] = {};
-  if (!attr2[dev & 63]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_strip_update_mfma_kernel<DT, DD>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, int(shm2));
-    attr2[dev & 63] = true;
-  }
-  hipLaunchKernelGGL((dense_strip_update_mfma_kernel<DT, DD>), dim3(1, v.B), dim3(256), shm2, s, v, args, K);
+  hipLaunchKernelGGL((dense_correct_mfma_kernel<DT, DD>), dim3(v.B), dim3(256), shm1, s, v, args, K);
   mark(4);
 }
 
