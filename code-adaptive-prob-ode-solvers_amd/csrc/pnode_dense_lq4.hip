@@ -257,14 +257,35 @@ __global__ __launch_bounds__(512) void dense_lq4_mfma_kernel(const DenseView v, 
         }
         asm volatile("" ::: "memory");
       }
-      if (lane == 0) {
-        double pl[kMaxN], pil[kMaxN];
-        precond_rt(nn, sarg.dt, K, pl, pil);
+      {
+        // one table entry per lane, in registers (a single lane filling the tables through local arrays took 25 k cycles
+        // at the head of every trajectory); the powers are formed by the multiplication sequence of precond_rt: same bits
+        const double adt = fabs(sarg.dt);
         double* cw = coefS[it & 1];
-        double* pw = pSS[it & 1];
-        for (int i = 0; i < nn; ++i)
-          for (int k = 0; k < nn; ++k) cw[i * kMaxN + k] = (k >= i) ? K.a[i][k] * pil[k] : 0.0;
-        for (int i = 0; i < kMaxN; ++i) pw[i] = (i < nn) ? pl[i] : 0.0;
+        double* pw_out = pSS[it & 1];
+#pragma unroll
+        for (int e0 = 0; e0 < kMaxN * kMaxN; e0 += 64) {
+          const int e = e0 + lane;
+          if (e < kMaxN * kMaxN) {
+            const int i = e / kMaxN, k = e % kMaxN;
+            double val = 0.0;
+            if (i < nn && k < nn && k >= i) {
+              double pw = sqrt(adt);
+              for (int m = nn - 1; m > k; --m) pw *= adt;
+              val = K.a[i][k] * (K.fact[k] / pw);
+            }
+            cw[e] = val;
+          }
+        }
+        if (lane < kMaxN) {
+          double val = 0.0;
+          if (lane < nn) {
+            double pw = sqrt(adt);
+            for (int m = nn - 1; m > lane; --m) pw *= adt;
+            val = pw / K.fact[lane];
+          }
+          pw_out[lane] = val;
+        }
       }
       lds_done();
       if (lane == 0) *(volatile lds_int*)&prepS = it + 1;
