@@ -300,6 +300,13 @@ __global__ __launch_bounds__(512) void dense_lq4_mfma_kernel(const DenseView v, 
     if (gi == 1) {
 #pragma unroll 1
       for (int k = 0; k < 4; ++k) {
+        // The two wavefronts j of the two groups share a SIMD, and v_mfma_f64 shares the SIMD's FP64 pipe with the DPP FMAs of the sweep.
+        // While the other group runs a chain, its wavefront j is on the critical path from the publication of panel j - 1 until it has
+        // published panel j (8.4 k cycles of MFMA + 16.4 k of DPP FMAs that nothing should share): I apply panel j - 1 only once
+        // panel j is out. (No cycle: its publication waits for marks I set before I entered this phase. Measured: 662 k -> 594 k
+        // cycles per trajectory. s_setprio does not arbitrate the matrix core; a flag raised and polled around the critical
+        // application only moved the collision into the sweep.)
+        if (k == j - 1) spin_ge(&pubS[j], base + 1);
         apply_panel(0, k, 4 + j);
         mark_done(k, base + 1);
       }
@@ -392,6 +399,7 @@ __global__ __launch_bounds__(512) void dense_lq4_mfma_kernel(const DenseView v, 
       if (has_trailing) {
 #pragma unroll 1
         for (int k = 0; k < 4; ++k) {
+          if (k == j - 1) spin_ge(&pubS[j], base + P + 2);  // (stay off the SIMD while its other wavefront is the chain's, see the prologue)
           apply_panel(P + 1, k, 4 * (P + 2) + j);
           mark_done(k, base + P + 2);
         }
