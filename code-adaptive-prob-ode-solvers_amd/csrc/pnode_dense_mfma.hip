@@ -724,6 +724,21 @@ __global__ __launch_bounds__(256, 2) void dense_correct_mfma_kernel(DenseView v,
   const IwpConst& K = *Kc;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
+#ifdef PNODE_TIMING_BUILD
+  // diagnostic build only: cycle sums by phase of wavefront 0, written behind the LQ's stamps in the S scratch
+  unsigned long long ck_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long ck_prev = __builtin_amdgcn_s_memtime();
+#define CK_STAMP(slot)                                             \
+  do {                                                             \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();  \
+    ck_acc[slot] += now_ - ck_prev;                                \
+    ck_prev = now_;                                                \
+  } while (0)
+#else
+#define CK_STAMP(slot) \
+  do {                 \
+  } while (0)
+#endif
   double p[kMaxN], pinv[kMaxN];
   precond_rt(v.n, arg.dt, K, p, pinv);
   const double p0 = p[0], p1 = p[1];
@@ -749,6 +764,7 @@ __global__ __launch_bounds__(256, 2) void dense_correct_mfma_kernel(DenseView v,
     }
   }
   __syncthreads();
+  CK_STAMP(0);
 #pragma unroll
   for (int it = 0; it < NT; ++it) {
     const int tile = wv + 4 * it;
@@ -761,6 +777,7 @@ __global__ __launch_bounds__(256, 2) void dense_correct_mfma_kernel(DenseView v,
     }
   }
   __syncthreads();  // everyone is done with J and T in LDS
+  CK_STAMP(1);
   // ---- life 2: F in LDS (and in global memory); F[:, d:2d] = p1 T[d:2d, d:2d] (lower triangular block)
 #pragma unroll
   for (int it = 0; it < NT; ++it) {
@@ -781,6 +798,7 @@ __global__ __launch_bounds__(256, 2) void dense_correct_mfma_kernel(DenseView v,
     F[a * W2 + d + c] = val;
   }
   __syncthreads();
+  CK_STAMP(2);
   constexpr int NLT = DD * (DD + 1) / 2, NS = (NLT + 3) / 4;  // lower tiles of S, and per wavefront
   auto tile_of = [](int t, int& ta, int& tb) {  // t-th lower tile in row-major order
     ta = 0;
@@ -802,6 +820,7 @@ __global__ __launch_bounds__(256, 2) void dense_correct_mfma_kernel(DenseView v,
     st[it] = acc;
   }
   __syncthreads();  // everyone is done with F in LDS
+  CK_STAMP(3);
   // ---- life 3: S, Cholesky, substitution
 #pragma unroll
   for (int it = 0; it < NS; ++it) {
@@ -815,7 +834,9 @@ __global__ __launch_bounds__(256, 2) void dense_correct_mfma_kernel(DenseView v,
   }
   __threadfence_block();
   __syncthreads();
+  CK_STAMP(4);
   lds_cholesky_blocked<DD, LD>(Sm, tid);
+  CK_STAMP(5);
   // ---- W = C^-1 F as a blocked triangular solve on the matrix core (it was one thread per column: 2 d^2 LDS reads per thread,
   // bound by the LDS issue rate). (a) inverses of the 16 x 16 diagonal blocks of C, one thread per column of a block;
   // (b) w = C^-1 z by one wavefront; (c) every wavefront owns whole 16-column tiles of F: for the block rows i = 0 .. DD-1
@@ -876,6 +897,7 @@ __global__ __launch_bounds__(256, 2) void dense_correct_mfma_kernel(DenseView v,
     }
   }
   __syncthreads();  // every wavefront is done with C and the inverse diagonal blocks: W takes their place in LDS
+  CK_STAMP(6);
   double* Fw = gbuf;  // [d][LDF]   life 4
 #pragma unroll
   for (int tt = 0; tt < NMY; ++tt) {
@@ -889,6 +911,13 @@ __global__ __launch_bounds__(256, 2) void dense_correct_mfma_kernel(DenseView v,
   }
   __syncthreads();
   strip_update_body<DT, DD>(v, arg, K, b, Fw, tvs, red);
+  CK_STAMP(7);
+#ifdef PNODE_TIMING_BUILD
+  if (tid == 0) {
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(v.S + size_t(b) * d * d) + 64;
+    for (int i = 0; i < 8; ++i) dbg[i] = ck_acc[i];
+  }
+#endif
 }
 
 bool dense_mfma_supported(const DenseView& v) {
