@@ -145,4 +145,70 @@ __device__ __forceinline__ void pivot_sweep(double (&X)[4 * DT], double (&tfrow)
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// In-place variant: plain row-Householder LQ of a strip whose pivot columns lie INSIDE the strip (the measurement update's
+// F = [C 0] Q, pnode_dense_mfma.hip). Panel `gp` (= the 16-row strip number, < 4) has its pivots in the columns 16 gp + C,
+// i.e. in register X[C] of the lanes of column group gp. On entry to pivot C the columns before 16 gp + C are zero in the rows
+// >= C (earlier pivot columns are cleared as they are extracted, the columns before the panel by the caller).
+//   reflector C:  v_C = scl_C * xhat_C,  xhat_C = [0 .. 0, 1 / scl_C (pivot column), x_C (columns beyond)],  H_C = I - tau_C v_C^T v_C
+// The rows stay unscaled in the registers (the pivot entry 1 / scl_C = -beta tau is stored in place), so that the panel
+// applies to other strips as a plain product with no separate unit part.
+// tpp_row[C] <- C-factor entry [row r][column C of the panel];  tfrow[C]: compact-WY factor as in pivot_step.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int C, int DT>
+__device__ __forceinline__ void pivot_step_inplace(double (&X)[4 * DT], double (&tfrow)[kNB], double* __restrict__ tpp_row,
+                                                   double& myscl, int gp, int r_, int g_) {
+  int r = r_, g = g_;
+  asm volatile("" : "+v"(r), "+v"(g));
+  const bool pivcol = g == gp;
+  // the strip's entries in the pivot column, delivered to every lane of their row; cleared in the rows >= C
+  const double t_r = sum_over_groups(pivcol ? X[C] : 0.0);
+  X[C] = (pivcol && r >= C) ? 0.0 : X[C];
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+  for (int e = 0; e < 4 * DT; e += 16)
+    dot16<C>(a0, a1, a2, a3, X[e], X[e + 1], X[e + 2], X[e + 3], X[e + 4], X[e + 5], X[e + 6], X[e + 7], X[e + 8], X[e + 9],
+             X[e + 10], X[e + 11], X[e + 12], X[e + 13], X[e + 14], X[e + 15]);
+  const double dotv = sum_over_groups((a0 + a1) + (a2 + a3));  // x_r . x_C over the columns beyond the pivot
+  const double xx = bcast16<C>(dotv);
+  const double alpha = bcast16<C>(t_r);
+  double tauc = 0.0, scale = 0.0, beta = alpha;
+  {
+    const double nrm2 = fma(alpha, alpha, xx);
+    const double rs = fast_rsqrt(nrm2);
+    const double sgn = copysign(1.0, alpha);
+    const double t1 = fma(fabs(alpha), rs, 1.0);
+    const bool refl = xx != 0.0;
+    beta = refl ? -sgn * nrm2 * rs : alpha;
+    tauc = refl ? t1 : 0.0;
+    scale = refl ? sgn * rs * fast_rcp(t1) : 0.0;
+  }
+  const double gr = fma(scale, dotv, t_r);  // (row r) . v_C
+  const double w = tauc * gr;
+  const double nws = (r > C) ? -(w * scale) : 0.0;
+  tpp_row[C] = (r > C) ? t_r - w : ((r == C) ? beta : 0.0);
+  {
+    const double u = (r < C) ? myscl * gr : 0.0;  // v_r . v_C for the finished reflectors r < C
+    double acc = 0.0;
+    tf_accumulate<0, C>(acc, u, tfrow);
+    tfrow[C] = (r < C) ? -tauc * acc : ((r == C) ? tauc : 0.0);
+  }
+  myscl = (r == C) ? scale : myscl;
+  asm volatile("" : "+v"(tfrow[C]), "+v"(myscl));
+#pragma unroll
+  for (int e = 0; e < 4 * DT; e += 16)
+    upd16<C>(X[e], X[e + 1], X[e + 2], X[e + 3], X[e + 4], X[e + 5], X[e + 6], X[e + 7], X[e + 8], X[e + 9], X[e + 10], X[e + 11],
+             X[e + 12], X[e + 13], X[e + 14], X[e + 15], nws);
+  X[C] = (pivcol && r == C) ? -(beta * tauc) : X[C];  // 1 / scl_C = alpha - beta = -beta tau  (0 without a reflection)
+}
+
+template <int C, int DT>
+__device__ __forceinline__ void pivot_sweep_inplace(double (&X)[4 * DT], double (&tfrow)[kNB], double* __restrict__ tpp_row,
+                                                    double& myscl, int gp, int r, int g) {
+  if constexpr (C < kNB) {
+    pivot_step_inplace<C, DT>(X, tfrow, tpp_row, myscl, gp, r, g);
+    pivot_sweep_inplace<C + 1, DT>(X, tfrow, tpp_row, myscl, gp, r, g);
+  }
+}
+
 }  // namespace pnode

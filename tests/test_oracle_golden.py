@@ -64,6 +64,28 @@ def test_vdp_step_count_lies_inside_the_rounding_ensemble(golden):
     assert n_ref >= counts.min() - 10
 
 
+# relative deviation allowed up to accepted point k (measured: 9e-15, 1.1e-13, 1.4e-11, 8.3e-9, 1.4e-6, 1.1e-3 at the stiff jump, t = 5.87)
+VDP_REPLAY_PROFILE = ((60, 1e-13), (100, 1e-12), (200, 2e-10), (800, 1e-7), (2400, 2e-5), (2912, 2e-2))
+VDP_REPLAY_PROFILE_ORACLE = ((60, 5e-14), (100, 5e-13), (200, 1e-10), (800, 5e-8), (2400, 5e-6), (2912, 5e-3))
+
+
+def test_vdp_fixed_grid_replay_pins_dense_ekf1_over_the_whole_reference_run(golden):
+    """The reference replays its own accepted grid with solve_fixed_grid (vdp.py:88-91): no controller, hence no chaotic grid
+    selection. The oracle on that grid against vdp_baseline_solution.npy over ALL 2 912 points pins the dense predict / correct
+    arithmetic over the whole run (the adaptive tests above only pin a prefix). The deviation grows with the stiffness of the
+    problem (largest at the jump of the relaxation oscillation, t = 5.87), not with a wrong constant."""
+    g = golden["vdp"]
+    vf = V.van_der_pol_order2(1e3)
+    cfg = po.SolverConfig(nu=4, model="dense", correction="ts1", strategy="filter", calibration="dynamic")
+    tc = tcoeffs(vf, [np.array([2.0]), np.array([0.0])], 4)
+    sol = po.solve_fixed_grid(cfg, oracle_problem(vf), po.initial_state(cfg, tc, 0.0), g["grid"])
+    ref = g["solution"][:, 0]
+    assert sol.u.shape[0] == len(ref) == 2912
+    rel = np.abs(sol.u[:, 0] - ref) / np.abs(ref)
+    for k, tol in VDP_REPLAY_PROFILE_ORACLE:
+        assert np.max(rel[:k]) < tol, (k, np.max(rel[:k]), tol)
+
+
 @pytest.mark.parametrize("N", [4, 16, 32, 64])
 def test_brusselator_checkpoint_solution(golden, N):
     """Isotropic EKF0 nu=4, fixed-point smoother, dynamic calibration, tol 1e-8, 200 checkpoints
