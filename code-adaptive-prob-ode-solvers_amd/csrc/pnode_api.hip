@@ -187,6 +187,7 @@ struct pnode_batch {
   StepArg* hArgs = nullptr;     // pinned
   InterpArg* hIargs = nullptr;  // pinned
   double* hErr = nullptr;       // pinned
+  int32_t* hFault = nullptr;    // pinned [4]: hand-shake failure of the one-launch LQ (pnode_dense_lq4.hip)
   // host bookkeeping, per trajectory
   std::vector<double> t_sf, t_if, dt_pending;
   std::vector<int8_t> s_sf, s_if, s_pr;
@@ -216,6 +217,7 @@ int pnode_destroy(pnode_batch* h) {
   if (h->hArgs) (void)hipHostFree(h->hArgs);
   if (h->hIargs) (void)hipHostFree(h->hIargs);
   if (h->hErr) (void)hipHostFree(h->hErr);
+  if (h->hFault) (void)hipHostFree(h->hFault);
   if (h->hFp0) (void)hipHostFree(h->hFp0);
   if (h->hFp1) (void)hipHostFree(h->hFp1);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -302,6 +304,8 @@ int pnode_create(const pnode_config* cfg, pnode_batch** out) {
   HIP_TRY_H(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->zArgs), h->hArgs, 0));
   HIP_TRY_H(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->zErr), h->hErr, 0));
   HIP_TRY_H(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->zIargs), h->hIargs, 0));
+  HIP_TRY_H(hipHostMalloc(reinterpret_cast<void**>(&h->hFault), 4 * sizeof(int32_t)));
+  std::memset(h->hFault, 0, 4 * sizeof(int32_t));
   HIP_TRY_H(hipHostMalloc(reinterpret_cast<void**>(&h->hFp0), B * sizeof(FpArg)));
   HIP_TRY_H(hipHostMalloc(reinterpret_cast<void**>(&h->hFp1), B * sizeof(FpArg)));
   HIP_TRY_H(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->zFp0), h->hFp0, 0));
@@ -406,6 +410,7 @@ int pnode_create(const pnode_config* cfg, pnode_batch** out) {
     }
     v.atol = h->dAtol; v.rtol = h->dRtol; v.prm = nprm ? h->dPrm : nullptr; v.errnorm = h->zErr;
     v.user_f = h->dUserF; v.user_J = h->dUserJ;
+    HIP_TRY_H(hipHostGetDevicePointer(reinterpret_cast<void**>(&v.fault), h->hFault, 0));
   }
   h->t_sf.assign(B, 0.0);
   h->t_if.assign(B, 0.0);
@@ -446,7 +451,8 @@ int pnode_set_initial(pnode_batch* h, const double* tcoeffs, const double* t0, c
       HIP_TRY(hipStreamSynchronize(h->stream));
     }
   } else {
-    HIP_TRY(hipMemsetAsync(h->dn.U, 0, B * D * D * sizeof(double), h->stream));
+    // every slot: the paths store the factor in different layouts, and a handle may change path after set_initial
+    HIP_TRY(hipMemsetAsync(h->dn.U, 0, size_t(h->dn.nslots) * B * D * D * sizeof(double), h->stream));
     if (h->dn.fixedpoint) {
       std::vector<double> eye(B * D * D, 0.0);
       for (size_t b = 0; b < B; ++b)
@@ -480,6 +486,20 @@ int pnode_set_tolerances(pnode_batch* h, const double* atol, const double* rtol)
   HIP_TRY(hipMemcpy(h->dAtol, atol, B * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->dRtol, rtol, B * sizeof(double), hipMemcpyHostToDevice));
   return PNODE_OK;
+}
+
+// After a stream synchronisation: a hand-shake of the one-launch LQ that ran into its spin limit is a device error, never a
+// numerical result (the kernel drains and fills the outputs with NaN, which would otherwise read as a failed ODE).
+static int check_fault(pnode_batch* h) {
+  if (!h->hFault || !h->hFault[0]) return PNODE_OK;
+  static const char* kind[3] = {"panel / stored-strip flag", "LDS slot hand-over", "coefficient tables"};
+  const int what = h->hFault[3] / 8, wave = h->hFault[3] % 8;
+  const std::string msg = "LQ hand-shake timed out (" + std::string(kind[what < 3 && what >= 0 ? what : 0]) + "), trajectory " +
+                          std::to_string(h->hFault[1]) + ", awaited value " + std::to_string(h->hFault[2]) + ", wavefront " +
+                          std::to_string(wave) + ": the state of the batch is undefined, call pnode_set_initial";
+  std::memset(h->hFault, 0, 4 * sizeof(int32_t));
+  h->initialised = false;
+  return fail(PNODE_EDEVICE, msg);
 }
 
 static void enqueue_step(pnode_batch* h, const StepArg* dargs, double* errnorm = nullptr) {
@@ -517,7 +537,7 @@ static int advance_rounds_device(pnode_batch* h, TrajCtl* hCtl, const ControlPar
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(hCtl, h->dCtl, B * sizeof(TrajCtl), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
-  return PNODE_OK;
+  return check_fault(h);
 }
 
 int pnode_attempt_step(pnode_batch* h, const double* dt, const uint8_t* active, double* err_norm_out) {
@@ -551,6 +571,7 @@ int pnode_attempt_step(pnode_batch* h, const double* dt, const uint8_t* active, 
   if (h->step_timing) HIP_TRY(hipEventRecord(h->ev1, h->stream));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
+  if (int rc = check_fault(h)) return rc;
   for (size_t b = 0; b < B; ++b)
     if (active[b]) err_norm_out[b] = h->hErr[b];
   return PNODE_OK;
@@ -1015,6 +1036,7 @@ int pnode_solve_fixed_grid(pnode_batch* h, const double* grid, int32_t G, int32_
   if (e == hipSuccess) e = hipGetLastError();
   cleanup();
   if (e != hipSuccess) return fail(PNODE_EDEVICE, hipGetErrorString(e));
+  if (int rc = check_fault(h)) return rc;
   for (size_t b = 0; b < B; ++b) {
     const double* gr = per_traj ? grid + b * G : grid;
     h->s_sf[b] = sf[b];
@@ -1073,13 +1095,10 @@ int pnode_read_factor(pnode_batch* h, int32_t which, double* out) {
   for (size_t b = 0; b < B; ++b) {
     HIP_TRY(hipMemcpy(tmp.data(), base + (size_t(slot_of(h, which, b)) * B + b) * m * m, m * m * sizeof(double),
                       hipMemcpyDeviceToHost));
-    if (h->dense && dense_state_factor_tiled(h->dn)) {  // L in the register order of the 16-row strips: de-tile, hand out R = L^T
-      const size_t DT = m / 16;
+    if (h->dense && dense_state_factor_tiled(h->dn)) {  // Ls (D x (D - d)) in the register order of the 16-row strips: hand out R = [Ls | 0]^T
       for (size_t i = 0; i < m; ++i)      // row of L
-        for (size_t j = 0; j < m; ++j) {  // column of L
-          const size_t s = i >> 4, r = i & 15, T = j >> 6, g = (j >> 4) & 3, e = j & 15;
-          out[b * m * m + j * m + i] = tmp[((s * 2 * DT + 8 * T + (e >> 1)) * 64 + r + 16 * g) * 2 + (e & 1)];
-        }
+        for (size_t j = 0; j < m; ++j)    // column of L
+          out[b * m * m + j * m + i] = tiled_factor_entry(tmp.data(), int(i), int(j), int(m), h->cfg.d);
     } else if (h->dense) {  // stored as L (Sigma = L L^T): hand out R = L^T
       for (size_t i = 0; i < m; ++i)
         for (size_t j = 0; j < m; ++j) out[b * m * m + i * m + j] = tmp[j * m + i];
@@ -1237,6 +1256,13 @@ int pnode_set_generic_path(pnode_batch* h, int32_t enabled) {
   h->dn.user_generic = enabled == 1;
   h->dn.force_large = enabled == 2;
   h->dn.lq_two_launch = enabled == 3;
+  return PNODE_OK;
+}
+
+int pnode_debug_set_lq_spin_limit(pnode_batch* h, int32_t polls) {
+  if (!h || polls < 0) return fail(PNODE_EINVAL, "bad argument");
+  if (!h->dense) return fail(PNODE_EINVAL, "the one-launch LQ belongs to the dense model");
+  h->dn.lq_spin_limit = polls;
   return PNODE_OK;
 }
 

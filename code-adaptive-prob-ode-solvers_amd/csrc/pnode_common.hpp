@@ -110,10 +110,20 @@ __device__ __forceinline__ double fast_rcp(double x) {
   return y;
 }
 
-// Element index of L[row][col] in the strip ("tiled") order of the MFMA path (pnode_mfma_common.hpp), run-time DT = D / 16.
-__host__ __device__ inline size_t tiled_index_rt(int row, int col, int DT) {
+// State factor of the handles that run the register-resident MFMA kernels (pnode_mfma_common.hpp). The measurement update on a
+// noise-free observation leaves a covariance of rank D - d, and the MFMA path stores a factor with that many columns:
+//      Sigma = Ls Ls^T,   Ls (D x (D - d)) = [ L^- Q2 (d dense columns) | columns >= 2d of the lower-triangular L^- ],
+// Q2 an orthonormal basis of the null space of F = H L^- inside its 2d non-zero columns. The column count is padded to whole
+// 64-column super-tiles (zero columns), DC = number of 16-column tiles; element (row, col) of Ls sits at tiled_index_rt(row, col, DC):
+// the register order of the 16-row strips.
+__host__ __device__ inline int tiled_col_tiles(int D, int d) { return ((D - d + 63) / 64) * 4; }
+__host__ __device__ inline size_t tiled_index_rt(int row, int col, int DC) {
   const int s = row >> 4, r = row & 15, T = col >> 6, g = (col >> 4) & 3, e = col & 15;
-  return ((size_t(s) * (2 * DT) + 8 * T + (e >> 1)) * 64 + r + 16 * g) * 2 + (e & 1);
+  return ((size_t(s) * (2 * DC) + 8 * T + (e >> 1)) * 64 + r + 16 * g) * 2 + (e & 1);
+}
+// The same factor seen as a D x D matrix [Ls | 0] (what the generic kernels and the read-back hand out).
+__host__ __device__ inline double tiled_factor_entry(const double* L, int row, int col, int D, int d) {
+  return col < D - d ? L[tiled_index_rt(row, col, tiled_col_tiles(D, d))] : 0.0;
 }
 
 // Rotate the row x (length N) into the upper-triangular R (N x N) with Givens rotations:

@@ -183,7 +183,7 @@ __global__ __launch_bounds__(kThreads) void dense_lq_input_kernel(DenseView v, c
     for (int c = threadIdx.x; c < D; c += kThreads) {
       double acc = 0.0;
       for (int kk = i; kk < n; ++kk)
-        acc += K.a[i][kk] * pinv[kk] * L[tiled ? tiled_index_rt(kk * d + q, c, D / 16) : size_t(kk * d + q) * D + c];
+        acc += K.a[i][kk] * pinv[kk] * (tiled ? tiled_factor_entry(L, kk * d + q, c, D, d) : L[size_t(kk * d + q) * D + c]);
       Mt[size_t(r) * D + c] = acc;
       const int j = c / d, q2 = c % d;
       T[size_t(r) * D + c] = (q2 == q && j <= i) ? sigma * K.qsT[j][i] : 0.0;
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(kThreads) void dense_ckfac_store_kernel(DenseView v
     const double* L = v.U + (size_t(a.s1) * v.B + b) * D * D;
     const bool tiled = v.u_tiled_now != 0;
     for (int r = blockIdx.x; r < D; r += gridDim.x)
-      for (int c = threadIdx.x; c < D; c += kThreads) out[size_t(r) * D + c] = L[tiled ? tiled_index_rt(r, c, D / 16) : size_t(r) * D + c];
+      for (int c = threadIdx.x; c < D; c += kThreads) out[size_t(r) * D + c] = tiled ? tiled_factor_entry(L, r, c, D, d) : L[size_t(r) * D + c];
     return;
   }
   double p[kMaxN], pinv[kMaxN];

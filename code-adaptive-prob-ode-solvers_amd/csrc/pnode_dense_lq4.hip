@@ -30,7 +30,7 @@
 namespace pnode {
 namespace lq4 {
 
-constexpr int kSpinLimit = 1 << 21;
+constexpr int kSpinLimit = 1 << 21;  // default bound of every wait (polls); DenseView::lq_spin_limit overrides it (diagnostics)
 // The words the wavefronts talk through are accessed through pointers that CARRY the LDS address space: a volatile access
 // through a generic pointer is not rewritten by the address-space inference and becomes a flat_load / flat_store.
 using lds_int = __attribute__((address_space(3))) int;
@@ -61,7 +61,9 @@ __global__ __launch_bounds__(512) void dense_lq4_mfma_kernel(const DenseView v, 
   static_assert(DT % 4 == 0, "whole 64-row blocks");
   static_assert((2 * 16 * DD) % 64 == 0, "a pass is all below or all beyond column 2d");
   constexpr int D = 16 * DT, d = 16 * DD, NBLK = DT / 4;
-  constexpr int LDV = D + 1;  // odd: the A-operand reads of the G phase (16 rows x 4 column groups) spread over the banks
+  // Mt = (Abar P^-1 (x) I) Ls has the D - d columns of the rank-deficient state factor (pnode_common.hpp), padded to DC tiles
+  constexpr int DC = mfma_col_tiles(DT, DD), WC = 16 * DC;
+  constexpr int LDV = WC + 1;  // odd: the A-operand reads of the G phase (16 rows x 4 column groups) spread over the banks
   __shared__ double Vx[4 * kNB * LDV];
   __shared__ double TfS[4 * kNB * kNB];
   __shared__ double sclS[4 * kNB];
@@ -104,15 +106,27 @@ __global__ __launch_bounds__(512) void dense_lq4_mfma_kernel(const DenseView v, 
   const double* pS = pSS[0];
 
   volatile lds_int* abort_word = (volatile lds_int*)&abortS;
+  const int spin_limit = v.lq_spin_limit > 0 ? v.lq_spin_limit : kSpinLimit;
+  // A wait that runs into its limit is a synchronisation FAILURE, not a numerical result: it is recorded in the handle's fault
+  // words (pinned host memory; the API returns PNODE_EDEVICE after the stream synchronisation), every wait of the launch then
+  // falls through so that the grid drains, and the outputs of the trajectories the workgroup still takes are NaN.
+  auto timed_out = [&](int n, int what, int target) {
+    if (n <= spin_limit && !__builtin_amdgcn_readfirstlane(*abort_word)) return false;
+    if (n > spin_limit && (tid & 63) == 0 && v.fault) {
+      v.fault[1] = b;
+      v.fault[2] = target;
+      v.fault[3] = 8 * what + wv;
+      __atomic_store_n(v.fault, 1, __ATOMIC_RELEASE);
+    }
+    *abort_word = 1;
+    return true;
+  };
   auto spin_ge = [&](int* f_, int target) {
     volatile lds_int* f = (volatile lds_int*)f_;
     int n = 0;
     while (__builtin_amdgcn_readfirstlane(*f) < target) {
       __builtin_amdgcn_s_sleep(2);
-      if ((++n & 255) == 0 && (n > kSpinLimit || __builtin_amdgcn_readfirstlane(*abort_word))) {
-        *abort_word = 1;
-        break;
-      }
+      if ((++n & 255) == 0 && timed_out(n, 0, target)) break;
     }
     asm volatile("" ::: "memory");
   };
@@ -129,10 +143,7 @@ __global__ __launch_bounds__(512) void dense_lq4_mfma_kernel(const DenseView v, 
       const int mine = (lane < 8) ? *(volatile lds_int*)&doneS[8 * k + lane] : 0x7fffffff;
       if (!__any(mine < G)) break;
       __builtin_amdgcn_s_sleep(2);
-      if ((++n & 255) == 0 && (n > kSpinLimit || __builtin_amdgcn_readfirstlane(*abort_word))) {
-        *abort_word = 1;
-        break;
-      }
+      if ((++n & 255) == 0 && timed_out(n, 1, G)) break;
     }
     asm volatile("" ::: "memory");
   };
@@ -154,7 +165,7 @@ __global__ __launch_bounds__(512) void dense_lq4_mfma_kernel(const DenseView v, 
     return t;
   };
 
-  double X[4 * DT];  // my strip: X[16 T + e] = M[row0 + r][64 T + 16 g + e]
+  double X[4 * DC];  // my strip: X[16 T + e] = M[row0 + r][64 T + 16 g + e]
 
   auto load_strip = [&](int st_, bool from_state) {
     const int ln = opaque(tid & 63);
@@ -165,13 +176,13 @@ __global__ __launch_bounds__(512) void dense_lq4_mfma_kernel(const DenseView v, 
       // rows of L at the same time
       const int ib = j0 / d;
 #pragma unroll
-      for (int e = 0; e < 4 * DT; ++e) X[e] = 0.0;
+      for (int e = 0; e < 4 * DC; ++e) X[e] = 0.0;
 #pragma unroll
-      for (int T4 = 0; T4 < DT / 4; ++T4) {
+      for (int T4 = 0; T4 < DC / 4; ++T4) {
 #pragma unroll 1
         for (int k = nn - 1; k >= ib; --k) {
           const double ck = coef[ib * kMaxN + k];
-          const double2* __restrict__ lrow = reinterpret_cast<const double2*>(Lsrc) + (size_t((k * d + j0 % d) / kNB) * (2 * DT) + 8 * T4) * 64 + ln;
+          const double2* __restrict__ lrow = reinterpret_cast<const double2*>(Lsrc) + (size_t((k * d + j0 % d) / kNB) * (2 * DC) + 8 * T4) * 64 + ln;
           double2 tmp[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) tmp[e] = lrow[e * 64];
@@ -183,9 +194,9 @@ __global__ __launch_bounds__(512) void dense_lq4_mfma_kernel(const DenseView v, 
         }
       }
     } else {
-      const double2* __restrict__ src = reinterpret_cast<const double2*>(Mt) + size_t(st_) * (2 * DT) * 64 + ln;
+      const double2* __restrict__ src = reinterpret_cast<const double2*>(Mt) + size_t(st_) * (2 * DC) * 64 + ln;
 #pragma unroll
-      for (int pp = 0; pp < 2 * DT; ++pp) {
+      for (int pp = 0; pp < 2 * DC; ++pp) {
         const double2 t2 = src[pp * 64];
         X[2 * pp] = t2.x;
         X[2 * pp + 1] = t2.y;
@@ -194,9 +205,9 @@ __global__ __launch_bounds__(512) void dense_lq4_mfma_kernel(const DenseView v, 
   };
   auto store_strip = [&](int st_) {
     const int ln = opaque(tid & 63);
-    double2* __restrict__ dst = reinterpret_cast<double2*>(Mt) + size_t(st_) * (2 * DT) * 64 + ln;
+    double2* __restrict__ dst = reinterpret_cast<double2*>(Mt) + size_t(st_) * (2 * DC) * 64 + ln;
 #pragma unroll
-    for (int pp = 0; pp < 2 * DT; ++pp) dst[pp * 64] = double2{X[2 * pp], X[2 * pp + 1]};
+    for (int pp = 0; pp < 2 * DC; ++pp) dst[pp * 64] = double2{X[2 * pp], X[2 * pp + 1]};
   };
   // Columns >= 2d of L^- are not touched by the measurement update (F = H L^- has 2d non-zero columns): the passes that
   // produce them write p_row * T straight into the destination slot of the state factor.
@@ -209,13 +220,13 @@ __global__ __launch_bounds__(512) void dense_lq4_mfma_kernel(const DenseView v, 
     const int r = opaque(lane & 15), g = opaque(lane >> 4);
     const int j0 = kNB * st_, cp = 64 * pass + kNB * k;
     double4_t tv;
-    apply_panel_to_strip_pipelined<DT, LDV>(X, Vx + k * kNB * LDV, TfS + k * kNB * kNB, sclS + k * kNB, t0_tile(j0, cp, r, g), tv, r, g);
+    apply_panel_to_strip_pipelined<DC, LDV>(X, Vx + k * kNB * LDV, TfS + k * kNB * kNB, sclS + k * kNB, t0_tile(j0, cp, r, g), tv, r, g);
     tv = transpose_groups(tv);  // lane (r, g): columns cp + 4 g .. cp + 4 g + 3 of row j0 + r
     const bool direct = is_direct(pass);
     const double osc = direct ? pS[(j0 + r) / d] : 1.0;
     const double2 lo2{osc * tv[0], osc * tv[1]}, hi2{osc * tv[2], osc * tv[3]};
-    if (direct) {  // strip order of the state factor: two pairs per lane, 16 lanes of a pair contiguous
-      double* base = Ldst + tiled_index<DT>(j0 + r, cp + 4 * g);
+    if (direct) {  // strip order of the state factor (column c of L^- is column c - d of Ls): two pairs per lane, 16 lanes of a pair contiguous
+      double* base = Ldst + tiled_index<DC>(j0 + r, cp + 4 * g - d);
       *reinterpret_cast<double2*>(base) = lo2;
       *reinterpret_cast<double2*>(base + 128) = hi2;  // next pair: + 64 lanes x 2 doubles
     } else {
@@ -250,10 +261,7 @@ __global__ __launch_bounds__(512) void dense_lq4_mfma_kernel(const DenseView v, 
           const int mine = (lane < 8) ? *(volatile lds_int*)&trajS[lane] : 0x7fffffff;
           if (!__any(mine < it - 1)) break;
           __builtin_amdgcn_s_sleep(4);
-          if ((++n & 255) == 0 && (n > kSpinLimit || __builtin_amdgcn_readfirstlane(*abort_word))) {
-            *abort_word = 1;
-            break;
-          }
+          if ((++n & 255) == 0 && timed_out(n, 2, it - 1)) break;
         }
         asm volatile("" ::: "memory");
       }
@@ -336,14 +344,14 @@ __global__ __launch_bounds__(512) void dense_lq4_mfma_kernel(const DenseView v, 
         for (int m = 0; m < kNB; ++m) tfrow[m] = 0.0;
         double* tpp_row = TppS + wv * kNB * kNB + r * kNB;
         __builtin_amdgcn_s_setprio(3);
-        pivot_sweep<0, DT>(X, tfrow, tpp_row, myscl, alpha, r);
+        pivot_sweep<0, DC>(X, tfrow, tpp_row, myscl, alpha, r);
         __builtin_amdgcn_s_setprio(0);
         st.mark(3);
         wait_slot_free(j, base + P);  // every wavefront is done with this slot's panels of the passes before
         st.mark(4);
         double* Vp = Vx + j * kNB * LDV;
 #pragma unroll
-        for (int T4 = 0; T4 < DT / 4; ++T4)
+        for (int T4 = 0; T4 < DC / 4; ++T4)
 #pragma unroll
           for (int e = 0; e < 16; ++e) Vp[r * LDV + 64 * T4 + 16 * g + e] = X[16 * T4 + e];
         if (g == 0) {
@@ -364,7 +372,7 @@ __global__ __launch_bounds__(512) void dense_lq4_mfma_kernel(const DenseView v, 
 #pragma unroll
           for (int q = 0; q < 4; q += 2) {
             const double2 t2{osc * o4[q], osc * o4[q + 1]};
-            double* dstp = direct ? Ldst + tiled_index<DT>(row, cp + 4 * g + q) : T + size_t(row) * D + cp + 4 * g + q;
+            double* dstp = direct ? Ldst + tiled_index<DC>(row, cp + 4 * g + q - d) : T + size_t(row) * D + cp + 4 * g + q;
             *reinterpret_cast<double2*>(dstp) = t2;  // (4 g + q is even: the pair is contiguous in both layouts)
           }
         }

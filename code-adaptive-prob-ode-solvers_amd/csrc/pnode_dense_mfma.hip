@@ -15,7 +15,7 @@
 //
 // Reference anchors: strategy_filter + correction_ts1 + solver_dynamic
 // (/root/reference/experiments/1_van_der_pol/vdp.py:62-66); arithmetic restated in oracle/pn_oracle.py.
-#include "pnode_mfma_common.hpp"
+#include "pnode_lq_sweep.hpp"
 
 namespace pnode {
 
@@ -143,12 +143,13 @@ __device__ __forceinline__ void factor_panel(double* rows, const PanelScratch& p
 
 // FIRST = true : pass 0 only, reading the state factor L (Mt formed on the fly), writing Mt rows 32.. and T
 // FIRST = false: passes 1 .. DT/2 - 1 from Mt.   (FIRST = false with first_pass = 0: all passes from Mt)
-template <int DT, bool FIRST>
+template <int DT, int DD, bool FIRST>
 __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, const StepArg* __restrict__ args,
                                                              const IwpConst* __restrict__ Kc, int first_pass) {
   static_assert(DT % 4 == 0, "the HBM strip layout needs D % 64 == 0");
   constexpr int D = 16 * DT;
-  constexpr int LDV = D + 1;  // 2*LDV = 2 (mod 64) dwords: conflict-free A-operand reads in the G phase
+  constexpr int DC = mfma_col_tiles(DT, DD), WC = 16 * DC;  // columns of Mt: the rank-deficient state factor (pnode_common.hpp)
+  constexpr int LDV = WC + 1;  // 2*LDV = 2 (mod 64) dwords: conflict-free A-operand reads in the G phase
   __shared__ double Vx[2 * kNB * LDV];
   __shared__ double TppS[2 * kNB * kNB];
   __shared__ double TfS[2 * kNB * kNB];
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
     if (!carried) {
       // the 32 rows of the pass's two panels, read in the register order of their strips (coalesced) and scattered into Vx:
       // pair pp of lane ln of strip sl holds M[16 sl + (ln & 15)][64 (pp / 8) + 16 (ln >> 4) + 2 (pp % 8) .. + 1]
-      constexpr int NL2 = 2 * kNB * D / 512;
+      constexpr int NL2 = 2 * kNB * WC / 512;
       double2 t2[NL2];
       if constexpr (fused) {
         // pass 0: rows 0 .. 31 lie in derivative block 0 (d >= 32): Mt = sum_k coef[0][k] L[k d + row]; k outermost, so the
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
 #pragma unroll
         for (int e = 0; e < NL2; ++e) t2[e].x = t2[e].y = 0.0;
         for (int k = 0; k < nn; ++k) {
-          const double2* __restrict__ src = reinterpret_cast<const double2*>(Lsrc) + size_t(k * d / kNB) * (2 * DT) * 64;
+          const double2* __restrict__ src = reinterpret_cast<const double2*>(Lsrc) + size_t(k * d / kNB) * (2 * DC) * 64;
           const double ck = coef[k];
           double2 lv[NL2];
 #pragma unroll
@@ -232,14 +233,14 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
           }
         }
       } else {
-        const double2* __restrict__ src = reinterpret_cast<const double2*>(Mt) + size_t(c0 / kNB) * (2 * DT) * 64;
+        const double2* __restrict__ src = reinterpret_cast<const double2*>(Mt) + size_t(c0 / kNB) * (2 * DC) * 64;
 #pragma unroll
         for (int e = 0; e < NL2; ++e) t2[e] = src[tid + 256 * e];
       }
 #pragma unroll
       for (int e = 0; e < NL2; ++e) {
         const int idx = tid + 256 * e;
-        const int sl = idx / (2 * DT * 64), rem = idx % (2 * DT * 64), pp = rem / 64, ln = rem % 64;
+        const int sl = idx / (2 * DC * 64), rem = idx % (2 * DC * 64), pp = rem / 64, ln = rem % 64;
         const int col = 64 * (pp / 8) + 16 * (ln >> 4) + 2 * (pp % 8);
         Vx[(kNB * sl + (ln & 15)) * LDV + col] = t2[e].x;
         Vx[(kNB * sl + (ln & 15)) * LDV + col + 1] = t2[e].y;
@@ -247,14 +248,14 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
     }
     __syncthreads();
     // ---- panel A
-    factor_panel<DT, LDV>(VA, psA, Gm, Nm, sigma * K.qsT[c0 / d][c0 / d], tid);
+    factor_panel<DC, LDV>(VA, psA, Gm, Nm, sigma * K.qsT[c0 / d][c0 / d], tid);
     // ---- panel B rows <- reflectors of A (rows live in LDS; natural column order 16 tt + m)
     {
       const double4_t t0v = t0_tile(c0 + kNB, c0);
       // G^T = V_A V_B^T: each wavefront contracts a quarter of the columns; the four partial tiles are summed in a
       // fixed order (bit-reproducible) through LDS that is idle between the two panel factorisations
       double4_t ar0 = {0.0, 0.0, 0.0, 0.0}, ar1 = ar0;
-      constexpr int SQ = D / 16;  // k-steps (of 4 columns) per wavefront
+      constexpr int SQ = WC / 16;  // k-steps (of 4 columns) per wavefront
 #pragma unroll 8
       for (int s = SQ * wv; s < SQ * (wv + 1); s += 2) {
         ar0 = MFMA64(VA[r * LDV + 4 * s + g], VB[r * LDV + 4 * s + g], ar0);
@@ -282,13 +283,13 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int row = c0 + kNB + r, col = c0 + g + 4 * q;
-          if (direct) Ldst[tiled_index<DT>(row, col)] = pS[row / d] * (t0v[q] - w4[q]);
+          if (direct) Ldst[tiled_index<DC>(row, col - d)] = pS[row / d] * (t0v[q] - w4[q]);
           else T[size_t(row) * D + col] = t0v[q] - w4[q];
         }
       }
       w4 = w4 * sc;
       __syncthreads();  // every wave has read all of B before anyone overwrites its tiles
-      for (int tt = wv; tt < DT; tt += 4) {
+      for (int tt = wv; tt < DC; tt += 4) {
         double4_t c4;
 #pragma unroll
         for (int q = 0; q < 4; ++q) c4[q] = VB[r * LDV + 16 * tt + g + 4 * q];
@@ -300,15 +301,15 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
       __syncthreads();
     }
     // ---- panel B
-    factor_panel<DT, LDV>(VB, psB, Gm, Nm, sigma * K.qsT[(c0 + kNB) / d][(c0 + kNB) / d], tid);
+    factor_panel<DC, LDV>(VB, psB, Gm, Nm, sigma * K.qsT[(c0 + kNB) / d][(c0 + kNB) / d], tid);
     // ---- diagonal blocks of T
     {
       const int i = tid >> 4, j = tid & 15;
       if (j <= i) {
         const size_t oa = size_t(c0 + i) * D + c0 + j, ob = size_t(c0 + kNB + i) * D + c0 + kNB + j;
         if (direct) {
-          Ldst[tiled_index<DT>(c0 + i, c0 + j)] = pS[(c0 + i) / d] * psA.Tpp[i * kNB + j];
-          Ldst[tiled_index<DT>(c0 + kNB + i, c0 + kNB + j)] = pS[(c0 + kNB + i) / d] * psB.Tpp[i * kNB + j];
+          Ldst[tiled_index<DC>(c0 + i, c0 + j - d)] = pS[(c0 + i) / d] * psA.Tpp[i * kNB + j];
+          Ldst[tiled_index<DC>(c0 + kNB + i, c0 + kNB + j - d)] = pS[(c0 + kNB + i) / d] * psB.Tpp[i * kNB + j];
         } else {
           T[oa] = psA.Tpp[i * kNB + j];
           T[ob] = psB.Tpp[i * kNB + j];
@@ -319,20 +320,20 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
     const int nstrips = DT - 2 * (P + 1);
     // Mt (scratch private to the LQ) is stored in the register order of the strips: every load / store instruction of a
     // wavefront covers 1 KB of contiguous memory (a row-major strip makes each lane touch a cache line of its own)
-    auto mt_pair = [&](int j0, int pp) { return reinterpret_cast<double2*>(Mt) + (size_t(j0 / kNB) * (2 * DT) + pp) * 64 + lane; };
-    auto load_strip = [&](int st, double (&X)[4 * DT]) {
+    auto mt_pair = [&](int j0, int pp) { return reinterpret_cast<double2*>(Mt) + (size_t(j0 / kNB) * (2 * DC) + pp) * 64 + lane; };
+    auto load_strip = [&](int st, double (&X)[4 * DC]) {
       const int j0 = c0 + 2 * kNB + kNB * st;
       if constexpr (fused) {
         const int ib = j0 / d;
 #pragma unroll
-        for (int T4 = 0; T4 < DT / 4; ++T4) {
+        for (int T4 = 0; T4 < DC / 4; ++T4) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) X[16 * T4 + e] = 0.0;
 #pragma unroll 1
           for (int k = ib; k < nn; ++k) {
             const double ck = coef[ib * kMaxN + k];
             // (rows k d + q of the state factor form whole strips: 16 | d)
-            const double2* __restrict__ lrow = reinterpret_cast<const double2*>(Lsrc) + (size_t((k * d + j0 % d) / kNB) * (2 * DT) + 8 * T4) * 64 + lane;
+            const double2* __restrict__ lrow = reinterpret_cast<const double2*>(Lsrc) + (size_t((k * d + j0 % d) / kNB) * (2 * DC) + 8 * T4) * 64 + lane;
 #pragma unroll
             for (int e = 0; e < 16; e += 2) {
               const double2 t2 = lrow[(e / 2) * 64];
@@ -343,23 +344,23 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
         }
       } else
 #pragma unroll
-      for (int pp = 0; pp < 2 * DT; ++pp) {
+      for (int pp = 0; pp < 2 * DC; ++pp) {
         const double2 t2 = *mt_pair(j0, pp);
         X[2 * pp] = t2.x;
         X[2 * pp + 1] = t2.y;
       }
     };
-    auto apply_both = [&](int st, double (&X)[4 * DT]) {
+    auto apply_both = [&](int st, double (&X)[4 * DC]) {
       const int j0 = c0 + 2 * kNB + kNB * st;
       double4_t ta, tb;
-      apply_panel_to_strip<DT, LDV>(X, VA, psA.Tf, psA.scl, t0_tile(j0, c0), ta, r, g);
-      apply_panel_to_strip<DT, LDV>(X, VB, psB.Tf, psB.scl, t0_tile(j0, c0 + kNB), tb, r, g);
+      apply_panel_to_strip<DC, LDV>(X, VA, psA.Tf, psA.scl, t0_tile(j0, c0), ta, r, g);
+      apply_panel_to_strip<DC, LDV>(X, VB, psB.Tf, psB.scl, t0_tile(j0, c0 + kNB), tb, r, g);
       if (direct) {
         const double osc = pS[(j0 + r) / d];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          Ldst[tiled_index<DT>(j0 + r, c0 + g + 4 * q)] = osc * ta[q];
-          Ldst[tiled_index<DT>(j0 + r, c0 + kNB + g + 4 * q)] = osc * tb[q];
+          Ldst[tiled_index<DC>(j0 + r, c0 + g + 4 * q - d)] = osc * ta[q];
+          Ldst[tiled_index<DC>(j0 + r, c0 + kNB + g + 4 * q - d)] = osc * tb[q];
         }
       } else {
         double* Trow = T + size_t(j0 + r) * D + c0;
@@ -370,10 +371,10 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
         }
       }
     };
-    auto store_strip = [&](int st, const double (&X)[4 * DT]) {
+    auto store_strip = [&](int st, const double (&X)[4 * DC]) {
       const int j0 = c0 + 2 * kNB + kNB * st;
 #pragma unroll
-      for (int pp = 0; pp < 2 * DT; ++pp) {
+      for (int pp = 0; pp < 2 * DC; ++pp) {
         double2 t2;
         t2.x = X[2 * pp];
         t2.y = X[2 * pp + 1];
@@ -385,7 +386,7 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
     const bool carry = !FIRST && nstrips >= 2;
     const bool keeper = carry && wv < 2;
     const int nmine = nstrips > wv ? (nstrips - wv + 3) / 4 : 0;
-    double X[4 * DT];
+    double X[4 * DC];
     for (int it = 0; it < nmine; ++it) {
       const bool last = it + 1 == nmine;
       const int st = keeper ? (last ? wv : wv + 4 * (it + 1)) : wv + 4 * it;
@@ -396,7 +397,7 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
     __syncthreads();  // every wavefront is done with the reflectors in Vx
     if (keeper) {
 #pragma unroll
-      for (int T4 = 0; T4 < DT / 4; ++T4)
+      for (int T4 = 0; T4 < DC / 4; ++T4)
 #pragma unroll
         for (int e = 0; e < 16; ++e) Vx[(kNB * wv + r) * LDV + 64 * T4 + 16 * g + e] = X[16 * T4 + e];
     }
@@ -590,21 +591,21 @@ __global__ __launch_bounds__(256) void dense_begin_mfma_kernel(DenseView v, cons
   if (tid == 0) v.sig_new[b] = v.dynamic ? sigma_hat : v.sigma[size_t(arg.src) * sB + b];
 }
 
-// Strip update: Y^T = W X^T, X^T -= W^T Y^T on the first 2d columns, copy of the rest, mean update,
-// and (block 0: rows of the zeroth derivative) the normalised error norm.
-// Second half of the measurement-update kernel (it was a kernel of its own, with W and tv handed over through global memory):
-// W (d x 2d, row stride LDF) and tv = W^T C^-1 z are in LDS when it is entered, all wavefronts past a barrier.
+// Second half of the measurement update: every 16-row strip of L^- = diag(p) T, first 2d columns, is rotated by the
+// reflectors of F (d / 16 panels, in LDS): X Q = [Y1 | Y2]. Y1 = L^- W^T feeds the mean, Y2 = L^- Q2 is the dense part of the
+// new rank-(D - d) state factor (columns 0 .. d-1 of Ls; the columns >= 2d of L^- were written by the LQ kernel as the columns
+// >= d of Ls, already scaled). Then (strip block 0: the rows of the zeroth derivative) the normalised error norm.
 template <int DT, int DD>
 __device__ __forceinline__ void strip_update_body(const DenseView& v, const StepArg& arg, const IwpConst& K, int b,
-                                                  const double* __restrict__ Fw, const double* __restrict__ tv, double* red) {
-  constexpr int D = 16 * DT, d = 16 * DD, W2 = 2 * d, LDF = W2 + 1;
+                                                  const double* __restrict__ Vf, const double* __restrict__ TfF,
+                                                  const double* __restrict__ sclF, const double* __restrict__ tv, double* red) {
+  constexpr int D = 16 * DT, d = 16 * DD, W2 = 2 * d, LDF = W2 + 1, DF = W2 / 16, DC = mfma_col_tiles(DT, DD);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const double* __restrict__ T = v.R + size_t(b) * D * D;
   const size_t sB = size_t(v.B);
   double* mdst = v.mean + (size_t(arg.dst) * sB + b) * D;
   double* __restrict__ Ln = v.U + (size_t(arg.dst) * sB + b) * D * D;
-  // one workgroup per trajectory walks all strip groups: W (64 KB) is staged once instead of once per group
   for (int st = wv; st < DT; st += 4) {
     const int row = 16 * st + r;
     const int iblk = (16 * st) / d;
@@ -619,7 +620,6 @@ __device__ __forceinline__ void strip_update_body(const DenseView& v, const Step
     // register strip in the HBM layout  X[16 T + 4 j + q] = p_r T[row][64 T + 16 g + 4 j + q]  (128 B per lane
     // and super-tile); T's upper triangle is stored as zeros, so no predicate is needed
     double X[W2 / 4];
-    double mpart = 0.0;
     const double* __restrict__ trow = T + size_t(row) * D + 16 * g;
 #pragma unroll
     for (int T4 = 0; T4 < W2 / 64; ++T4)
@@ -630,57 +630,30 @@ __device__ __forceinline__ void strip_update_body(const DenseView& v, const Step
         X[16 * T4 + e + 1] = pr * t2.y;
       }
 #pragma unroll
+    for (int pnl = 0; pnl < DD; ++pnl) {
+      double4_t unused;
+      apply_panel_to_strip<DF, LDF>(X, Vf + pnl * kNB * LDF, TfF + pnl * kNB * kNB, sclF + pnl * kNB, double4_t{0.0, 0.0, 0.0, 0.0},
+                                    unused, r, g);
+    }
+    // mean: m -= Y1 (C^-1 z); tv holds C^-1 z in its first d entries and zeros beyond
+    double mpart = 0.0;
+#pragma unroll
     for (int T4 = 0; T4 < W2 / 64; ++T4)
 #pragma unroll
       for (int e = 0; e < 16; ++e) mpart = fma(X[16 * T4 + e], tv[64 * T4 + 16 * g + e], mpart);
     mpart += __shfl_xor(mpart, 16, kWave);
     mpart += __shfl_xor(mpart, 32, kWave);
     if (g == 0) mdst[row] -= mpart;
-    double4_t yT[DD];
-#pragma unroll
-    for (int ta = 0; ta < DD; ++ta) {
-      double4_t a0 = {0.0, 0.0, 0.0, 0.0}, a1 = a0;
-#pragma unroll
-      for (int T4 = 0; T4 < W2 / 64; ++T4)
-#pragma unroll
-        for (int e = 0; e < 16; e += 2) {
-          const double* wrow = Fw + (16 * ta + r) * LDF + 64 * T4 + 16 * g + e;
-          a0 = MFMA64(wrow[0], X[16 * T4 + e], a0);
-          a1 = MFMA64(wrow[1], X[16 * T4 + e + 1], a1);
-        }
-      yT[ta] = a0 + a1;
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    const int coff = 16 * (r & 3) + (r >> 2);
-#pragma unroll
-    for (int T4 = 0; T4 < W2 / 64; ++T4) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        double4_t c4 = {X[16 * T4 + 4 * j], X[16 * T4 + 4 * j + 1], X[16 * T4 + 4 * j + 2], X[16 * T4 + 4 * j + 3]};
-#pragma unroll
-        for (int kk = 0; kk < d / 4; ++kk)
-          c4 = MFMA64(-Fw[(4 * kk + g) * LDF + 64 * T4 + 4 * j + coff], yT[kk >> 2][kk & 3], c4);
-        X[16 * T4 + 4 * j] = c4[0];
-        X[16 * T4 + 4 * j + 1] = c4[1];
-        X[16 * T4 + 4 * j + 2] = c4[2];
-        X[16 * T4 + 4 * j + 3] = c4[3];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
     {
-      // the state factor is stored in the register order of the strips (pnode_mfma_common.hpp): 1 KB per store instruction
-      double2* __restrict__ lrow = reinterpret_cast<double2*>(Ln) + size_t(st) * (2 * DT) * 64 + lane;
+      // Y2 = columns d .. 2d-1 of the rotated strip -> columns 0 .. d-1 of the state factor, in the register order of its strips
 #pragma unroll
       for (int T4 = 0; T4 < W2 / 64; ++T4)
 #pragma unroll
         for (int e = 0; e < 16; e += 2) {
-          double2 t2;
-          t2.x = X[16 * T4 + e];
-          t2.y = X[16 * T4 + e + 1];
-          lrow[(8 * T4 + e / 2) * 64] = t2;
+          const int col = 64 * T4 + 16 * g + e - d;
+          if (col >= 0) *reinterpret_cast<double2*>(Ln + tiled_index<DC>(row, col)) = double2{X[16 * T4 + e], X[16 * T4 + e + 1]};
         }
     }
-    // (columns >= 2d of these rows were written by the LQ kernel, already scaled)
   }
   {
     // error norm over u = m[0] (rows 0 .. d-1 were updated above)
@@ -701,23 +674,28 @@ __device__ __forceinline__ void strip_update_body(const DenseView& v, const Step
   }
 }
 
-// Measurement update, ONE kernel per trajectory: F = H L^-, S = F F^T = C C^T, W = C^-1 F, tv = W^T C^-1 z, then (strip_update_body)
-// L = L^- - (L^- W^T) W on the first 2d columns, the mean and the error norm. W and tv stay on chip (registers -> LDS).
+// Measurement update, ONE kernel per trajectory, by orthogonal transformations only (the reference's square-root correction:
+// QR of (H L^-)^T, strategy_filter + correction_ts1, /root/reference/experiments/1_van_der_pol/vdp.py:64-65):
+//   F = H L^- (d x 2d: L^- is lower triangular),  F = [C 0] Q^T by a blocked row-Householder LQ (S = C C^T is never formed),
+//   L^- Q = [Y1 | Y2 | columns >= 2d]:  gain K = Y1 C^-1, mean m = m^- - Y1 (C^-1 z), and [Y2 | columns >= 2d] is a factor of the
+//   updated covariance with D - d columns -- the observation is noise-free, the d directions of Y1 are known exactly afterwards.
+// The panels of the LQ (wavefront p sweeps strip p of F in registers, pnode_lq_sweep.hpp) stay in LDS for the strips of L^-.
 template <int DT, int DD>
 __global__ __launch_bounds__(256, 2) void dense_correct_mfma_kernel(DenseView v, const StepArg* __restrict__ args,
                                                               const IwpConst* __restrict__ Kc) {
-  constexpr int D = 16 * DT, d = 16 * DD, W2 = 2 * d, LD = d + 1, LDF = W2 + 1;
-  // One LDS buffer, three lives: (1) J and T[0:d, 0:d] staged for the MFMA that forms F (both were MFMA operands read
-  // straight from global memory before: one exposed L2/HBM latency per k-step), (2) F itself, d x 2d, the operand of
-  // S = F F^T, (3) S and its Cholesky factor. F and W also go to global memory for the column solve and the strip kernel.
+  constexpr int D = 16 * DT, d = 16 * DD, W2 = 2 * d, LD = d + 1, LDF = W2 + 1, DF = W2 / 16;
+  static_assert(DD <= 4, "one wavefront per 16-row strip of F; the pivot columns of a strip lie in the first super-tile");
+  // One LDS buffer, two lives: (1) J and T[0:d, 0:d] staged for the MFMA that forms F (2) F itself, d x 2d, whose strips become
+  // the reflector panels in place.
   extern __shared__ double gbuf[];
   double* Js = gbuf;            // [d][LD]      life 1
   double* Ts = gbuf + d * LD;   // [d][LD]      life 1
-  double* Fl = gbuf;            // [d][LDF]     life 2
-  double* Sm = gbuf;            // [d][LD]      life 3
-  double* wz = gbuf + 2 * d * LD;      // [d]   (beyond all three)
-  double* tvs = wz + d;                // [2d]  tv = W^T C^-1 z
-  double* red = tvs + W2;              // [4]
+  double* Fl = gbuf;            // [d][LDF]     life 2: F, then the reflector rows (unscaled, pivot entries 1 / scl)
+  double* TfF = gbuf + 2 * d * LD;     // [DD][16][16]  compact-WY factors of the panels   (beyond both lives)
+  double* sclF = TfF + DD * kNB * kNB; // [d]
+  double* tpp = sclF + d;              // [16][16]  diagonal block of C of the sweeping wavefront
+  double* wz = tpp + kNB * kNB;        // [2d]  C^-1 z, zeros beyond d
+  double* red = wz + W2;               // [4]
   const int b = blockIdx.x;
   const StepArg arg = args[b];
   if (!arg.active) return;
@@ -744,14 +722,13 @@ __global__ __launch_bounds__(256, 2) void dense_correct_mfma_kernel(DenseView v,
   const double p0 = p[0], p1 = p[1];
   const double* __restrict__ T = v.R + size_t(b) * D * D;
   const double* __restrict__ Jg = v.J + size_t(b) * d * d;
-  double* __restrict__ F = v.Ft + size_t(b) * d * D;  // [d][W2] used
   // ---- life 1: stage J and the lower-triangular T[0:d, 0:d] (coalesced), form F[:, 0:d] = p1 T[d:2d, 0:d] - p0 J T[0:d, 0:d]
   for (int idx = tid; idx < d * d; idx += 256) {
     const int a = idx / d, c = idx % d;
     Js[a * LD + c] = -p0 * Jg[idx];
     Ts[a * LD + c] = T[size_t(a) * D + c];  // (the upper part is stored as zeros)
   }
-  for (int j = tid; j < d; j += 256) wz[j] = v.z[size_t(b) * d + j];
+  for (int j = tid; j < W2; j += 256) wz[j] = j < d ? v.z[size_t(b) * d + j] : 0.0;
   constexpr int NT = (DD * DD + 3) / 4;  // F1 tiles per wavefront
   double4_t f1[NT];
 #pragma unroll
@@ -778,139 +755,80 @@ __global__ __launch_bounds__(256, 2) void dense_correct_mfma_kernel(DenseView v,
   }
   __syncthreads();  // everyone is done with J and T in LDS
   CK_STAMP(1);
-  // ---- life 2: F in LDS (and in global memory); F[:, d:2d] = p1 T[d:2d, d:2d] (lower triangular block)
+  // ---- life 2: F in LDS; F[:, d:2d] = p1 T[d:2d, d:2d] (lower triangular block)
 #pragma unroll
   for (int it = 0; it < NT; ++it) {
     const int tile = wv + 4 * it;
     if (tile < DD * DD) {
       const int ta = tile / DD, tc = tile % DD;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        Fl[(16 * ta + g + 4 * q) * LDF + 16 * tc + r] = f1[it][q];
-        F[(16 * ta + g + 4 * q) * W2 + 16 * tc + r] = f1[it][q];
-      }
+      for (int q = 0; q < 4; ++q) Fl[(16 * ta + g + 4 * q) * LDF + 16 * tc + r] = f1[it][q];
     }
   }
   for (int idx = tid; idx < d * d; idx += 256) {
     const int a = idx / d, c = idx % d;
-    const double val = (c <= a) ? p1 * T[size_t(d + a) * D + d + c] : 0.0;
-    Fl[a * LDF + d + c] = val;
-    F[a * W2 + d + c] = val;
+    Fl[a * LDF + d + c] = (c <= a) ? p1 * T[size_t(d + a) * D + d + c] : 0.0;
   }
   __syncthreads();
   CK_STAMP(2);
-  constexpr int NLT = DD * (DD + 1) / 2, NS = (NLT + 3) / 4;  // lower tiles of S, and per wavefront
-  auto tile_of = [](int t, int& ta, int& tb) {  // t-th lower tile in row-major order
-    ta = 0;
-    while ((ta + 1) * (ta + 2) / 2 <= t) ++ta;
-    tb = t - ta * (ta + 1) / 2;
-  };
-  double4_t st[NS];
+  // ---- blocked row-Householder LQ of F: wavefront w owns strip w (16 rows, all 2d columns) in registers
+  double X[4 * DF];
+  const bool owner = wv < DD;
+  if (owner) {
 #pragma unroll
-  for (int it = 0; it < NS; ++it) {
-    const int t = wv + 4 * it;
-    double4_t acc = {0.0, 0.0, 0.0, 0.0};
-    if (t < NLT) {
-      int ta, tb;
-      tile_of(t, ta, tb);
-#pragma unroll 8
-      for (int s = 0; s < W2 / 4; ++s)
-        acc = MFMA64(Fl[(16 * ta + r) * LDF + 4 * s + g], Fl[(16 * tb + r) * LDF + 4 * s + g], acc);
-    }
-    st[it] = acc;
+    for (int T4 = 0; T4 < DF / 4; ++T4)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) X[16 * T4 + e] = Fl[(kNB * wv + r) * LDF + 64 * T4 + 16 * g + e];
   }
-  __syncthreads();  // everyone is done with F in LDS
   CK_STAMP(3);
-  // ---- life 3: S, Cholesky, substitution
-#pragma unroll
-  for (int it = 0; it < NS; ++it) {
-    const int t = wv + 4 * it;
-    if (t < NLT) {
-      int ta, tb;
-      tile_of(t, ta, tb);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) Sm[(16 * ta + g + 4 * q) * LD + 16 * tb + r] = st[it][q];
-    }
-  }
-  __threadfence_block();
-  __syncthreads();
-  CK_STAMP(4);
-  lds_cholesky_blocked<DD, LD>(Sm, tid);
-  CK_STAMP(5);
-  // ---- W = C^-1 F as a blocked triangular solve on the matrix core (it was one thread per column: 2 d^2 LDS reads per thread,
-  // bound by the LDS issue rate). (a) inverses of the 16 x 16 diagonal blocks of C, one thread per column of a block;
-  // (b) w = C^-1 z by one wavefront; (c) every wavefront owns whole 16-column tiles of F: for the block rows i = 0 .. DD-1
-  //     R_i = F_i - sum_{j<i} C_ij W_j,  W_i = C_ii^-1 R_i
-  // with the tiles W_j in registers: the C/D fragment of a tile (lane (r, g), register s: row g + 4 s, column r) IS the B
-  // operand of the next product's k-chunk s, so no tile goes through LDS.
-  double* Dinv = gbuf + d * LD;  // [DD][16][17]   (the J/T staging area of life 1 is free now)
-  constexpr int LDI = kNB + 1;
-  if (tid < d) {
-    const int blk = tid / kNB, c = tid % kNB, o = kNB * blk;
-    double x[kNB];
-#pragma unroll
-    for (int a2 = 0; a2 < kNB; ++a2) x[a2] = (a2 == c) ? 1.0 : 0.0;
-#pragma unroll
-    for (int a2 = 0; a2 < kNB; ++a2) {
-      double acc = x[a2];
-#pragma unroll
-      for (int m = 0; m < a2; ++m) acc -= Sm[(o + a2) * LD + o + m] * x[m];
-      x[a2] = acc / Sm[(o + a2) * LD + o + a2];
-    }
-#pragma unroll
-    for (int a2 = 0; a2 < kNB; ++a2) Dinv[(blk * kNB + a2) * LDI + c] = x[a2];  // column c of C_blk^-1
-  }
-  lds_forward_vec_wave<d, LD>(Sm, wz, tid);  // (ends with a workgroup barrier: Dinv and wz are visible)
-  constexpr int NCT = W2 / kNB;  // column tiles of F
-  constexpr int NMY = (NCT + 3) / 4;  // per wavefront
-  double4_t w[NMY][DD];
-#pragma unroll
-  for (int tt = 0; tt < NMY; ++tt) {
-    const int ct = wv + 4 * tt;
-    if (ct < NCT) {
-#pragma unroll
-      for (int i = 0; i < DD; ++i) {
-        double4_t acc;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = F[(kNB * i + g + 4 * q) * W2 + kNB * ct + r];
-#pragma unroll
-        for (int jb = 0; jb < DD; ++jb) {
-          if (jb < i) {
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) acc = MFMA64(-Sm[(kNB * i + r) * LD + kNB * jb + 4 * s4 + g], w[tt][jb][s4], acc);
-          }
-        }
-        double4_t wi = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) wi = MFMA64(Dinv[(i * kNB + r) * LDI + 4 * s4 + g], acc[s4], wi);
-        w[tt][i] = wi;
-      }
-      // tv = W^T (C^-1 z) for my 16 columns: lane (r, g) holds the rows g + 4 q of every block row of column r
+#pragma unroll 1
+  for (int pnl = 0; pnl < DD; ++pnl) {
+    if (owner && wv == pnl) {
+      // my columns before the panel are final entries of C (row block wv): their share of the forward substitution
+      //   rhs = z - C[rows, 0 : 16 wv] (C^-1 z)[0 : 16 wv]
+      // is taken here, then they leave the strip (the reflectors of this panel act on the columns >= 16 wv only)
       double part = 0.0;
+      if (g < wv) {
 #pragma unroll
-      for (int i = 0; i < DD; ++i)
+        for (int e = 0; e < 16; ++e) {
+          part = fma(X[e], wz[16 * g + e], part);
+          X[e] = 0.0;
+        }
+      }
+      double rhs = wz[kNB * wv + r] - sum_over_groups(part);
+      double tfrow[kNB], myscl = 0.0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) part = fma(w[tt][i][q], wz[kNB * i + g + 4 * q], part);
-      part += __shfl_xor(part, 16, kWave);
-      part += __shfl_xor(part, 32, kWave);
-      if (g == 0) tvs[kNB * ct + r] = part;
+      for (int m = 0; m < kNB; ++m) tfrow[m] = 0.0;
+      double* tpp_row = tpp + r * kNB;
+      pivot_sweep_inplace<0, DF>(X, tfrow, tpp_row, myscl, wv, r, g);
+#pragma unroll
+      for (int T4 = 0; T4 < DF / 4; ++T4)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) Fl[(kNB * wv + r) * LDF + 64 * T4 + 16 * g + e] = X[16 * T4 + e];
+      if (g == 0) {
+        sclF[kNB * wv + r] = myscl;
+#pragma unroll
+        for (int m = 0; m < kNB; ++m) TfF[wv * kNB * kNB + r * kNB + m] = tfrow[m];
+      }
+      // forward substitution with the diagonal block (lower triangular, row r in tpp_row): lane r of every group alike
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      double crow[kNB];
+#pragma unroll
+      for (int m = 0; m < kNB; ++m) crow[m] = tpp_row[m];
+      double xsol = 0.0;
+      tri_forward16<0>(rhs, xsol, crow, r);
+      if (g == 0) wz[kNB * wv + r] = xsol;
     }
-  }
-  __syncthreads();  // every wavefront is done with C and the inverse diagonal blocks: W takes their place in LDS
-  CK_STAMP(6);
-  double* Fw = gbuf;  // [d][LDF]   life 4
-#pragma unroll
-  for (int tt = 0; tt < NMY; ++tt) {
-    const int ct = wv + 4 * tt;
-    if (ct < NCT) {
-#pragma unroll
-      for (int i = 0; i < DD; ++i)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) Fw[(kNB * i + g + 4 * q) * LDF + kNB * ct + r] = w[tt][i][q];
+    __syncthreads();
+    if (owner && wv > pnl) {
+      double4_t unused;
+      apply_panel_to_strip<DF, LDF>(X, Fl + pnl * kNB * LDF, TfF + pnl * kNB * kNB, sclF + pnl * kNB, double4_t{0.0, 0.0, 0.0, 0.0},
+                                    unused, r, g);
     }
   }
   __syncthreads();
-  strip_update_body<DT, DD>(v, arg, K, b, Fw, tvs, red);
+  CK_STAMP(6);
+  strip_update_body<DT, DD>(v, arg, K, b, Fl, TfF, sclF, wz, red);
   CK_STAMP(7);
 #ifdef PNODE_TIMING_BUILD
   if (tid == 0) {
@@ -935,13 +853,14 @@ static void launch_mfma(const DenseView& v, const StepArg* args, const IwpConst*
   if (!v.lq_two_launch && dense_lq4_supported(v)) {
     dense_launch_lq4(v, args, K, s);  // one launch, overlapping 64-row passes (pnode_dense_lq4.hip)
   } else {
-    hipLaunchKernelGGL((dense_lq2_mfma_kernel<DT, true>), dim3(v.B), dim3(256), 0, s, v, args, K, 0);
-    hipLaunchKernelGGL((dense_lq2_mfma_kernel<DT, false>), dim3(v.B), dim3(256), 0, s, v, args, K, 1);
+    hipLaunchKernelGGL((dense_lq2_mfma_kernel<DT, DD, true>), dim3(v.B), dim3(256), 0, s, v, args, K, 0);
+    hipLaunchKernelGGL((dense_lq2_mfma_kernel<DT, DD, false>), dim3(v.B), dim3(256), 0, s, v, args, K, 1);
   }
   mark(3);
   constexpr int d = 16 * DD;
   static_assert(DD <= 4, "the error norm is computed by strip block 0, which must cover the d rows of u");
-  const size_t shm1 = (size_t(2) * d * (d + 1) + 3 * d + 8) * sizeof(double);  // >= d (2d + 1) + 3d + 4: see the kernel
+  // 2 d (d + 1) >= d (2d + 1) for the two lives of the big buffer, then TfF, sclF, tpp, wz, red: see the kernel
+  const size_t shm1 = (size_t(2) * d * (d + 1) + size_t(DD) * 256 + d + 256 + 2 * d + 8) * sizeof(double);
   int dev = 0;
   (void)hipGetDevice(&dev);
   static bool attr1[64] = {};  // the opt-in to > 64 KB of dynamic LDS is per function AND per device

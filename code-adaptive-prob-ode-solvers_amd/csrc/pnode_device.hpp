@@ -42,6 +42,8 @@ struct DenseView {
   int B, d, k, n, D, K;
   int ts1, dynamic, vf_id, P, prm_per_traj;
   int force_generic;  // 1: never take the MFMA fast path (A/B testing)
+  int lq_spin_limit;  // > 0: bound (in polls) of every wait of the one-launch LQ, instead of its default (pnode_debug_set_lq_spin_limit)
+  int32_t* fault;     // [4] pinned host memory: {raised, trajectory, awaited value, 8 * kind + wavefront} of a hand-shake that timed out
   int lq_two_launch;  // 1: LQ of the MFMA fast path by the two-launch, 32-row-pass kernels (pnode_dense_mfma.hip) even where the
                       // one-launch kernel with overlapping 64-row passes (pnode_dense_lq4.hip) supports the shape (A/B testing)
   double* mean;   // [3][B][n][d]

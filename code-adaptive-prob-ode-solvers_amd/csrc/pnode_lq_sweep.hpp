@@ -211,4 +211,17 @@ __device__ __forceinline__ void pivot_sweep_inplace(double (&X)[4 * DT], double 
   }
 }
 
+// Forward substitution with a 16 x 16 lower-triangular block held one row per lane (crow = row r of the block, every 16-lane
+// DPP row alike): on exit xsol(lane r) = (block^-1 rhs)[r].
+template <int C>
+__device__ __forceinline__ void tri_forward16(double& rhs, double& xsol, const double (&crow)[kNB], int r) {
+  if constexpr (C < kNB) {
+    const double cand = rhs * fast_rcp(crow[C]);  // meaningful on row C
+    const double xc = bcast16<C>(cand);
+    xsol = (r == C) ? xc : xsol;
+    rhs = (r > C) ? fma(-crow[C], xc, rhs) : rhs;
+    tri_forward16<C + 1>(rhs, xsol, crow, r);
+  }
+}
+
 }  // namespace pnode

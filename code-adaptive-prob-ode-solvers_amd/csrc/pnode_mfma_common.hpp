@@ -51,17 +51,19 @@ __device__ __forceinline__ double row16_sum(double v) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// State factor of the handles that run the register-resident MFMA kernels: L (D x D) is stored in HBM in the REGISTER ORDER
+// State factor of the handles that run the register-resident MFMA kernels: Ls (D rows, 16 DC columns: the D - d columns of the
+// rank-(D - d) factor, pnode_common.hpp, padded with zero columns to whole super-tiles) is stored in HBM in the REGISTER ORDER
 // of the 16-row strips ("tiled"): lane l = r + 16 g of strip s holds, as its pair pp = 8 T + e / 2, the two elements
-//      L[16 s + r][64 T + 16 g + e], L[16 s + r][64 T + 16 g + e + 1]        (e even)
-// at double2 index (s * 2 DT + pp) * 64 + l. Every load / store instruction of a wavefront then covers 1 KB of contiguous
+//      Ls[16 s + r][64 T + 16 g + e], Ls[16 s + r][64 T + 16 g + e + 1]        (e even)
+// at double2 index (s * 2 DC + pp) * 64 + l. Every load / store instruction of a wavefront then covers 1 KB of contiguous
 // memory; in a row-major strip every lane touches a cache line of its own and the address unit serialises the 64 requests
 // (measured: 2 TB/s against 4.5 TB/s). pnode_read_factor de-tiles on the host.
 // ---------------------------------------------------------------------------------------------
-template <int DT>
-__device__ __forceinline__ size_t tiled_index(int row, int col) {  // element index (in doubles) of L[row][col]
+constexpr int mfma_col_tiles(int DT, int DD) { return ((16 * (DT - DD) + 63) / 64) * 4; }
+template <int DC>
+__device__ __forceinline__ size_t tiled_index(int row, int col) {  // element index (in doubles) of Ls[row][col]
   const int s = row >> 4, r = row & 15, T = col >> 6, g = (col >> 4) & 3, e = col & 15;
-  return ((size_t(s) * (2 * DT) + 8 * T + (e >> 1)) * 64 + r + 16 * g) * 2 + (e & 1);
+  return ((size_t(s) * (2 * DC) + 8 * T + (e >> 1)) * 64 + r + 16 * g) * 2 + (e & 1);
 }
 
 // 4 x 4 transpose of a C/D fragment among the four 16-lane rows of the wavefront: in, lane (r, g) holds columns g + 4 q of

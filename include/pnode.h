@@ -217,6 +217,12 @@ int pnode_last_step_ms(pnode_batch* h, float* ms_out);
  * factor in different layouts.
  * No environment variable influences the library: the choice is per handle, through this call only. */
 int pnode_set_generic_path(pnode_batch* h, int32_t enabled);
+/* Diagnostics of the one-launch LQ of the dense MFMA path (csrc/pnode_dense_lq4.hip): its wavefronts hand panels over through
+ * flag words in LDS, and every wait is a bounded spin. A wait that runs into its bound is reported by the call that synchronises
+ * with the device (pnode_attempt_step, pnode_advance_device, pnode_solve_*) as PNODE_EDEVICE with the trajectory and the awaited
+ * value in pnode_last_error -- never as NaN results; the batch must then be re-initialised. polls > 0 replaces the default
+ * bound (2^21 polls) so that tests can provoke the failure; 0 restores it. */
+int pnode_debug_set_lq_spin_limit(pnode_batch* h, int32_t polls);
 /* Enables HIP-event timing of attempt_step (all models). Dense model: also record HIP events between the kernels of a step (on the handle's stream) and
  * read the durations of the last attempt, ms_out[4] = {begin, lq_input, lq, correct}. */
 int pnode_set_phase_timing(pnode_batch* h, int32_t enabled);

@@ -1,0 +1,155 @@
+"""Round-3 GPU cases: the rank-(D - d) state factor of the MFMA path, path switches on a reused handle, the hand-shake
+time-out of the one-launch LQ as a device error, and the longer randomised comparison of the two LQ kernels (it was a script)."""
+
+import numpy as np
+import pn_oracle as po
+import pytest
+from helpers import brusselator_y0, oracle_problem, tcoeffs
+from probdiffeq_hip import _backend
+from probdiffeq_hip import vector_fields as V
+
+pytestmark = pytest.mark.gpu
+
+
+def relmax(a, b):
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+def _batch(vf, nu, B, path=0):
+    bt = _backend.Batch(batch=B, d=vf.d, nu=nu, ode_order=1, model="dense", correction="ts1", strategy="filter",
+                        calibration="dynamic", vf_id=vf.vf_id, vf_params=vf.param_array(), num_checkpoints=2)
+    if path:
+        bt.set_generic_path(path)
+    return bt
+
+
+@pytest.mark.parametrize("N,nu", [(16, 3), (16, 5), (32, 3)])
+def test_mfma_state_factor_has_rank_D_minus_d(hip_lib, N, nu):
+    """The measurement update of the MFMA path rotates the first 2d columns of L^- by the reflectors of F = H L^- and keeps the
+    D - d columns that carry covariance (the observation is noise-free: the other d are known exactly). What the read-back hands
+    out is R = [Ls | 0]^T: d zero rows, R^T R equal to the oracle's covariance, H Sigma H^T = 0 to rounding."""
+    vf = V.brusselator(N)
+    d, D = vf.d, (nu + 1) * vf.d
+    B = 3
+    y0 = np.stack([brusselator_y0(N, ph) for ph in (0.0, 0.4, 1.3)])
+    tc = tcoeffs(vf, [y0], nu)
+    bt = _batch(vf, nu, B)
+    bt.set_initial(np.stack(tc, axis=1), np.zeros(B), np.ones(B))
+    bt.set_tolerances(1e-5, 1e-5)
+    cfg = po.SolverConfig(nu=nu, model="dense", correction="ts1", strategy="filter", calibration="dynamic")
+    prob = oracle_problem(vf)
+    sts = [po.initial_state(cfg, [c[b] for c in tc], 0.0) for b in range(B)]
+    err = np.zeros(B)
+    for dt in (0.004, 0.007, 0.011):
+        bt.attempt_step(np.full(B, dt), np.ones(B, np.uint8), err)
+        bt.commit(np.ones(B, np.uint8))
+        sts = [po.step(cfg, prob, st, dt)[1] for st in sts]
+        R = bt.read_factor(0)
+        for b in range(B):
+            assert np.all(R[b][D - d:] == 0.0)  # the columns the factor does not have
+            cov = R[b].T @ R[b]
+            ref = sts[b].chol @ sts[b].chol.T
+            assert relmax(cov, ref) < 1e-6  # (sigma_hat carries 1e-7 relative: cancellation in z; nu = 5 reaches 3e-7)
+            # observed combination E1 - J E0 of the state: zero posterior variance
+            assert np.linalg.matrix_rank(R[b], tol=1e-9 * np.abs(R[b]).max()) <= D - d
+    bt.close()
+
+
+def test_reused_handle_may_switch_path_after_set_initial(hip_lib):
+    """A handle that has stepped on the generic kernels (row-major factor in all three slots), is re-initialised and switched to
+    the MFMA path (strip order, D - d columns) must give the results of a fresh handle: pnode_set_initial clears every slot."""
+    N, nu, B = 16, 3, 4
+    vf = V.brusselator(N)
+    y0 = np.stack([brusselator_y0(N, ph) for ph in np.linspace(0.0, 1.5, B)])
+    tc = np.stack(tcoeffs(vf, [y0], nu), axis=1)
+    dts = (0.004, 0.006, 0.009, 0.012)
+
+    def run(bt):
+        err = np.zeros(B)
+        errs = []
+        for dt in dts:
+            bt.attempt_step(np.full(B, dt), np.ones(B, np.uint8), err)
+            bt.commit(np.ones(B, np.uint8))
+            errs.append(err.copy())
+        R = bt.read_factor(0)
+        return np.array(errs), bt.read_mean(0), np.einsum("bji,bjk->bik", R, R)
+
+    reused = _batch(vf, nu, B, path=1)
+    reused.set_initial(tc, np.zeros(B), np.ones(B))
+    reused.set_tolerances(1e-5, 1e-5)
+    run(reused)  # every slot now holds a row-major factor
+    reused.set_initial(tc, np.zeros(B), np.ones(B))
+    reused.set_generic_path(0)
+    got = run(reused)
+    reused.close()
+    fresh = _batch(vf, nu, B)
+    fresh.set_initial(tc, np.zeros(B), np.ones(B))
+    fresh.set_tolerances(1e-5, 1e-5)
+    want = run(fresh)
+    fresh.close()
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+
+
+def test_lq_handshake_timeout_is_a_device_error_not_a_result(hip_lib):
+    """Every wait of the one-launch LQ is a bounded spin. With the bound set to one poll round the first real wait fails: the
+    step must come back as an error that names the hand-shake (PNODE_EDEVICE -> RuntimeError), not as NaN error norms that the
+    controller would read as a failed ODE. After re-initialisation the handle works again, bit for bit like a fresh one."""
+    N, nu, B = 32, 3, 6
+    vf = V.brusselator(N)
+    y0 = np.stack([brusselator_y0(N, ph) for ph in np.linspace(0.0, 1.0, B)])
+    tc = np.stack(tcoeffs(vf, [y0], nu), axis=1)
+    bt = _batch(vf, nu, B)
+    bt.set_initial(tc, np.zeros(B), np.ones(B))
+    bt.set_tolerances(1e-5, 1e-5)
+    bt.debug_set_lq_spin_limit(1)
+    err = np.zeros(B)
+    with pytest.raises(RuntimeError, match="hand-shake timed out"):
+        bt.attempt_step(np.full(B, 0.005), np.ones(B, np.uint8), err)
+    with pytest.raises(RuntimeError):  # the state is undefined until set_initial
+        bt.attempt_step(np.full(B, 0.005), np.ones(B, np.uint8), err)
+    bt.debug_set_lq_spin_limit(0)
+    bt.set_initial(tc, np.zeros(B), np.ones(B))
+    bt.attempt_step(np.full(B, 0.005), np.ones(B, np.uint8), err)
+    fresh = _batch(vf, nu, B)
+    fresh.set_initial(tc, np.zeros(B), np.ones(B))
+    fresh.set_tolerances(1e-5, 1e-5)
+    err2 = np.zeros(B)
+    fresh.attempt_step(np.full(B, 0.005), np.ones(B, np.uint8), err2)
+    assert np.all(np.isfinite(err)) and np.array_equal(err, err2)
+    bt.close()
+    fresh.close()
+
+
+def test_one_launch_lq_soak_against_two_launch_lq(hip_lib):
+    """The headline shape at the headline batch: D = 256, 1024 trajectories (four per persistent workgroup), 20 attempts with
+    random step sizes, activity masks and accept / reject decisions; the one-launch LQ against the two-launch LQ. Guards the
+    flag protocol of the persistent workgroups (trajectories skipped inside a workgroup's sequence, slot reuse across
+    trajectories) under the load it runs at."""
+    N, nu, B, ATT = 32, 3, 1024, 20
+    rng = np.random.default_rng(1000 * N + nu)
+    vf = V.brusselator(N)
+    y0 = np.stack([brusselator_y0(N, ph) for ph in rng.uniform(0.0, 2.0, B)])
+    tc = np.stack(tcoeffs(vf, [y0], nu), axis=1)
+    one, two = _batch(vf, nu, B), _batch(vf, nu, B, path=3)
+    for bt in (one, two):
+        bt.set_initial(tc, np.zeros(B), np.ones(B))
+        bt.set_tolerances(1e-5, 1e-5)
+    e1, e2 = np.zeros(B), np.zeros(B)
+    worst_e = worst_m = 0.0
+    for it in range(ATT):
+        dts = 0.004 * rng.uniform(0.5, 2.0, B)
+        act = (rng.uniform(size=B) < 0.8).astype(np.uint8)
+        acc = (act & (rng.uniform(size=B) < 0.85)).astype(np.uint8)
+        one.attempt_step(dts, act, e1)
+        two.attempt_step(dts, act, e2)
+        live = act.astype(bool)
+        assert np.all(np.isfinite(e1[live])), it
+        worst_e = max(worst_e, float(np.max(np.abs(e1[live] - e2[live]) / e2[live])))
+        one.commit(acc)
+        two.commit(acc)
+        m1, m2 = one.read_mean(0), two.read_mean(0)
+        worst_m = max(worst_m, float(np.max(np.abs(m1[:, 0] - m2[:, 0])) / np.max(np.abs(m2[:, 0]))))
+    one.close()
+    two.close()
+    assert worst_e < 1e-6 and worst_m < 1e-9, (worst_e, worst_m)
