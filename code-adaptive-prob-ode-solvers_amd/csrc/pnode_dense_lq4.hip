@@ -344,7 +344,7 @@ __global__ __launch_bounds__(512) void dense_lq4_mfma_kernel(const DenseView v, 
         for (int m = 0; m < kNB; ++m) tfrow[m] = 0.0;
         double* tpp_row = TppS + wv * kNB * kNB + r * kNB;
         __builtin_amdgcn_s_setprio(3);
-        pivot_sweep<0, DC>(X, tfrow, tpp_row, myscl, alpha, r);
+        pivot_sweep<0, DC>(X, tfrow, tpp_row, myscl, alpha);
         __builtin_amdgcn_s_setprio(0);
         st.mark(3);
         wait_slot_free(j, base + P);  // every wavefront is done with this slot's panels of the passes before
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(512) void dense_lq4_mfma_kernel(const DenseView v, 
           // diagonal block of T: lane (r, g) writes columns 4g .. 4g+3 of row r (zeros above the diagonal)
           double o4[4];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) o4[q] = tpp_row[4 * g + q];
+          for (int q = 0; q < 4; ++q) o4[q] = (4 * g + q <= r) ? tpp_row[4 * g + q] : 0.0;  // (the sweep leaves the upper triangle unwritten)
           const int row = cp + r;
           const bool direct = is_direct(P);
           const double osc = direct ? pS[row / d] : 1.0;

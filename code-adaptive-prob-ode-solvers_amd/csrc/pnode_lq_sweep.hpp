@@ -89,15 +89,77 @@ __device__ __forceinline__ void tf_accumulate(double& acc, double u, const doubl
   }
 }
 
+// Lane predicates of the sweep as LITERAL lane masks (lane l holds row l & 15): a select costs two v_cndmask_b32 with the mask
+// in an SGPR pair (s_mov_b64 on the scalar unit) instead of v_cmp + wait states + v_cndmask on the vector unit. The sweep is
+// bound by the number of vector instructions a wavefront issues between the FMAs (scripts/dpp_probe.hip: 5.6 cycles per DPP FMA,
+// 4 to 5 for everything else, one at a time), not by their latencies.
+constexpr unsigned long long rep4(unsigned v) {
+  const unsigned long long w = v & 0xFFFFu;
+  return w | (w << 16) | (w << 32) | (w << 48);
+}
+template <int C> constexpr unsigned long long kRowsBelow = rep4(0xFFFFu << (C + 1));  // r > C
+template <int C> constexpr unsigned long long kRowIs = rep4(1u << C);                   // r == C
+template <unsigned long long MASK>
+__device__ __forceinline__ double sel_mask(double a, double b) {  // lanes of MASK: a, others: b
+  const unsigned long long m = MASK;
+  unsigned lo, hi;
+  asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(lo) : "v"(__double2loint(b)), "v"(__double2loint(a)), "s"(m));
+  asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(hi) : "v"(__double2hiint(b)), "v"(__double2hiint(a)), "s"(m));
+  return __hiloint2double(hi, lo);
+}
+template <unsigned long long MASK>
+__device__ __forceinline__ double sel_mask_or_zero(double a) {  // lanes of MASK: a, others: 0
+  const unsigned long long m = MASK;
+  unsigned lo, hi;
+  asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(lo) : "v"(__double2loint(a)), "s"(m));
+  asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(hi) : "v"(__double2hiint(a)), "s"(m));
+  return __hiloint2double(hi, lo);
+}
+
+// Terms 4 Q .. 4 Q + 3 (those below C) of the T-factor recurrence acc_r += Tf[r][M] u_M: one DPP FMA per term, FOUR accumulators
+// so that the terms do not wait for each other (as a single chain every term cost 16 cycles: two wait states + the latency).
+// HAZARD (gfx950): a VGPR that a DPP instruction uses -- any operand -- must have been written at least two wait states earlier
+// when its writer is a VALU instruction; the compiler does not look into inline asm and may place a register copy right in
+// front of it (it does: scripts/sweep_probe.hip), so every asm block of DPP instructions starts with s_nop 1.
+#define PNODE_TF(a, m) "v_fmac_f64_dpp " a ", %[u], " m " row_newbcast:%[b" m "] row_mask:0xf bank_mask:0xf\n\t"
+template <int Q, int C>
+__device__ __forceinline__ void tf_block(double (&acc)[4], double u, const double (&tfrow)[kNB]) {
+  constexpr int M0 = 4 * Q, N = (C - M0 >= 4) ? 4 : C - M0;
+  if constexpr (N == 1)
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %[a0], %[u], %[t0] row_newbcast:%[m0] row_mask:0xf bank_mask:0xf"
+                 : [a0] "+v"(acc[0]) : [u] "v"(u), [t0] "v"(tfrow[M0]), [m0] "i"(M0));
+  else if constexpr (N == 2)
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %[a0], %[u], %[t0] row_newbcast:%[m0] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %[a1], %[u], %[t1] row_newbcast:%[m1] row_mask:0xf bank_mask:0xf"
+                 : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]) : [u] "v"(u), [t0] "v"(tfrow[M0]), [t1] "v"(tfrow[M0 + 1]), [m0] "i"(M0), [m1] "i"(M0 + 1));
+  else if constexpr (N == 3)
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %[a0], %[u], %[t0] row_newbcast:%[m0] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %[a1], %[u], %[t1] row_newbcast:%[m1] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %[a2], %[u], %[t2] row_newbcast:%[m2] row_mask:0xf bank_mask:0xf"
+                 : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2])
+                 : [u] "v"(u), [t0] "v"(tfrow[M0]), [t1] "v"(tfrow[M0 + 1]), [t2] "v"(tfrow[M0 + 2]), [m0] "i"(M0), [m1] "i"(M0 + 1), [m2] "i"(M0 + 2));
+  else if constexpr (N == 4)
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %[a0], %[u], %[t0] row_newbcast:%[m0] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %[a1], %[u], %[t1] row_newbcast:%[m1] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %[a2], %[u], %[t2] row_newbcast:%[m2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %[a3], %[u], %[t3] row_newbcast:%[m3] row_mask:0xf bank_mask:0xf"
+                 : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3])
+                 : [u] "v"(u), [t0] "v"(tfrow[M0]), [t1] "v"(tfrow[M0 + 1]), [t2] "v"(tfrow[M0 + 2]), [t3] "v"(tfrow[M0 + 3]), [m0] "i"(M0),
+                   [m1] "i"(M0 + 1), [m2] "i"(M0 + 2), [m3] "i"(M0 + 3));
+  if constexpr (M0 + 4 < C) tf_block<Q + 1, C>(acc, u, tfrow);
+}
+#undef PNODE_TF
+
 // Pivot C of the sweep. On entry rows 0 .. C are final (row C received its last update at pivot C - 1).
 //   v_C = [e_C ; scl_C x_C]  (x_C stays unscaled in the registers),  H_C = I - tau_C v_C^T v_C.
-// tpp_row[C] <- T[row r][column C of the panel]  (beta on the diagonal, -w below, 0 above), staged in LDS
+// tpp_row[C] <- T[row r][column C of the panel] for r >= C (beta on the diagonal, -w below; the entries of the rows r < C, zeros
+//              of the triangle, are NOT written as such: the reader masks them)
 // tfrow[C] <- Tf[r][C] of the compact-WY factor, H_0 ... H_C = I - V^T Tf V  (forward recurrence, dlarft)
+// A pivot row without a single non-zero entry is reflected like any other (v = e_C, tau = 2: the sign of column C flips);
+// 1e-200 keeps the reciprocal square root finite when the T0 pivot is zero too (output scale 0 and a zero factor).
 template <int C, int DT>
 __device__ __forceinline__ void pivot_step(double (&X)[4 * DT], double (&tfrow)[kNB], double* __restrict__ tpp_row, double& myscl,
-                                           double alpha, int r_) {
-  int r = r_;
-  asm volatile("" : "+v"(r));  // opaque: the per-pivot lane predicates are formed here, not hoisted out of the pass loop
+                                           double alpha) {
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
   for (int e = 0; e < 4 * DT; e += 16)
@@ -105,43 +167,45 @@ __device__ __forceinline__ void pivot_step(double (&X)[4 * DT], double (&tfrow)[
              X[e + 10], X[e + 11], X[e + 12], X[e + 13], X[e + 14], X[e + 15]);
   const double part = (a0 + a1) + (a2 + a3);
   const double dotv = sum_over_groups(part);  // every lane of row r holds x_r . x_C
-  const double xx = bcast16<C>(dotv);  // |x_C|^2
-  double tauc = 0.0, scale = 0.0, beta = alpha;
-  {
-    const double nrm2 = fma(alpha, alpha, xx);
-    const double rs = fast_rsqrt(nrm2);
-    const double sgn = copysign(1.0, alpha);
-    const double t1 = fma(fabs(alpha), rs, 1.0);
-    const bool refl = xx != 0.0;  // (NaN != 0: a NaN row propagates, like the reference's QR)
-    beta = refl ? -sgn * nrm2 * rs : alpha;
-    tauc = refl ? t1 : 0.0;
-    scale = refl ? sgn * rs * fast_rcp(t1) : 0.0;
+  const double xx = bcast16<C>(dotv);  // |x_C|^2   (NaN: a NaN row propagates, like the reference's QR)
+  const double nrm2 = fma(alpha, alpha, xx) + 1e-200;
+  const double rs = fast_rsqrt(nrm2);
+  const double beta = -copysign(nrm2 * rs, alpha);
+  const double tauc = fma(fabs(alpha), rs, 1.0);
+  const double scale = copysign(rs, alpha) * fast_rcp(tauc);
+  const double sa = scale * dotv;
+  const double w = tauc * sa;  // (the rows of one panel have no T0 entry in each other's columns)
+  const double nws = sel_mask_or_zero<kRowsBelow<C>>(-(w * scale));
+  tpp_row[C] = sel_mask<kRowIs<C>>(beta, -w);  // (the four lanes of a row store the same value)
+  double tfc;
+  if constexpr (C > 0) {
+    const double u = myscl * sa;  // v_r . v_C for the finished reflectors r < C; zero on the other rows (their myscl still is)
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    tf_block<0, C>(acc, u, tfrow);
+    const double ind = sel_mask_or_zero<kRowIs<C>>(1.0);
+    tfc = tauc * (ind - ((acc[0] + acc[1]) + (acc[2] + acc[3])));  // -tau acc on the rows r < C (acc is zero elsewhere: Tf is upper triangular)
+  } else {
+    tfc = sel_mask_or_zero<kRowIs<C>>(tauc);
   }
-  const double w = tauc * scale * dotv;  // (the rows of one panel have no T0 entry in each other's columns)
-  const double nws = (r > C) ? -(w * scale) : 0.0;
-  tpp_row[C] = (r > C) ? -w : ((r == C) ? beta : 0.0);  // (the four lanes of a row store the same value)
-  {
-    const double u = (r < C) ? myscl * scale * dotv : 0.0;  // v_r . v_C for the finished reflectors r < C
-    double acc = 0.0;
-    tf_accumulate<0, C>(acc, u, tfrow);
-    tfrow[C] = (r < C) ? -tauc * acc : ((r == C) ? tauc : 0.0);
-  }
-  myscl = (r == C) ? scale : myscl;
+  tfrow[C] = tfc;
+  myscl = sel_mask<kRowIs<C>>(scale, myscl);
   // pin the recurrence inside its pivot: without this the scheduler sinks all 120 broadcasts below the last asm block of the
   // sweep (they only feed the publication), spilling their operands on the way
   asm volatile("" : "+v"(tfrow[C]), "+v"(myscl));
+  if constexpr (C + 1 < kNB) {  // (the last pivot has no row left to update)
 #pragma unroll
-  for (int e = 0; e < 4 * DT; e += 16)
-    upd16<C>(X[e], X[e + 1], X[e + 2], X[e + 3], X[e + 4], X[e + 5], X[e + 6], X[e + 7], X[e + 8], X[e + 9], X[e + 10], X[e + 11],
-             X[e + 12], X[e + 13], X[e + 14], X[e + 15], nws);
+    for (int e = 0; e < 4 * DT; e += 16)
+      upd16<C>(X[e], X[e + 1], X[e + 2], X[e + 3], X[e + 4], X[e + 5], X[e + 6], X[e + 7], X[e + 8], X[e + 9], X[e + 10], X[e + 11],
+               X[e + 12], X[e + 13], X[e + 14], X[e + 15], nws);
+  }
 }
 
 template <int C, int DT>
 __device__ __forceinline__ void pivot_sweep(double (&X)[4 * DT], double (&tfrow)[kNB], double* __restrict__ tpp_row, double& myscl,
-                                            double alpha, int r) {
+                                            double alpha) {
   if constexpr (C < kNB) {
-    pivot_step<C, DT>(X, tfrow, tpp_row, myscl, alpha, r);
-    pivot_sweep<C + 1, DT>(X, tfrow, tpp_row, myscl, alpha, r);
+    pivot_step<C, DT>(X, tfrow, tpp_row, myscl, alpha);
+    pivot_sweep<C + 1, DT>(X, tfrow, tpp_row, myscl, alpha);
   }
 }
 
