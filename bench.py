@@ -41,6 +41,7 @@ TOL = 1e-6
 DT0 = 0.01
 FP64_PEAK_TFLOPS = 78.6  # MI355X fp64 vector = matrix peak
 HBM_PEAK_GBS = 8000.0
+PMC_SUMMARIES = ("r03_pmc_summary.json", "r02_pmc_summary.json")  # newest committed rocprofv3 --pmc summary first
 
 
 def problem_batch(B, offset=0, total=None):
@@ -56,20 +57,26 @@ def problem_batch(B, offset=0, total=None):
     return vf, tcs
 
 
-def algorithmic_flops_lq(D):
-    """Row-Householder LQ of the D x 2D stack [T | Mt] with T triangular: 2 D^3 (the
-    predict QR dominates; structure-aware count of the algorithm actually run)."""
-    return 2.0 * D**3
+def algorithmic_flops_lq(D, d):
+    """Row-Householder LQ of the stack [T | Mt], T triangular (D x D), Mt = (Abar P^-1 (x) I) Ls with the D - d columns of the
+    rank-(D - d) state factor (r03: the noise-free measurement update leaves rank D - d): reflector i has
+    1 + (D - d) entries and acts on the D - i rows below it -> 4 (D - d) D^2 / 2 = 2 D^2 (D - d). (r02 ran the same LQ on D
+    columns: 2 D^3; SURVEY 8(d)'s (10/3) D^3 is the unstructured QR of the 2D x D stack.)"""
+    return 2.0 * D * D * (D - d)
 
 
 def measured_traffic(kernel_prefix, batch):
     """HBM bytes per launch of the dominant kernel from the committed PMC summary
-    (profiles/r02_pmc_summary.json, produced on an MI355X by scripts/collect_profile.sh with separate
+    (profiles/r03_pmc_summary.json, produced on an MI355X by scripts/collect_profile.sh with separate
     --pmc passes; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md), scaled to this batch."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
-    try:
-        data = json.load(open(path))
-    except OSError:
+    data = None
+    for name in PMC_SUMMARIES:
+        try:
+            data = json.load(open(os.path.join(ROOT, "profiles", name)))
+            break
+        except OSError:
+            continue
+    if data is None:
         return None
     total = 0.0
     for name, v in data.items():  # the LQ runs as two launches (first pass + remaining passes): sum them
@@ -94,53 +101,53 @@ def _granted_cpus():
     return aff, quota
 
 
-def cpu_baseline(seconds=5.0, repeats=3):
+def _cpu_workers(n, seconds, backend, cores):
+    """n worker processes (oracle/cpu_baseline_worker.py), one trajectory and one pinned core each, started together."""
+    import subprocess
+
+    worker = os.path.join(ROOT, "oracle", "cpu_baseline_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(i), str(cores[i % len(cores)]) if cores else "-1", str(seconds), backend],
+                              stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True) for i in range(n)]
+    for p in procs:
+        assert p.stdout.readline().strip() == "ready"
+    for p in procs:
+        p.stdin.write("go\n")
+        p.stdin.flush()
+    res = [json.loads(p.stdout.readline()) for p in procs]
+    for p in procs:
+        p.wait()
+    return res
+
+
+def cpu_baseline(seconds=5.0, repeats=2):
     """The oracle ("port") timed on this host's cores on a bounded sample of the same workload:
     oracle/pn_oracle_c.c (C restatement of oracle/pn_oracle.py, checked against it in tests/test_oracle_c.py) with its
-    LAPACK / BLAS back end (blocked dgeqrf, dgemm, dtrsm of the OpenBLAS that scipy ships, one BLAS thread per OpenMP thread),
-    OpenMP with one trajectory per thread on every granted core, every thread running the adaptive loop for `seconds`; one
-    warm-up, then the best of `repeats` runs; the single-core figure next to it."""
-    import ctypes as C
-    import glob
-
+    LAPACK / BLAS back end (blocked dgeqrf, dgemm, dtrsm of the OpenBLAS that scipy ships, one BLAS thread), ONE PROCESS PER
+    GRANTED CORE, each pinned to its own core and running the adaptive loop of one trajectory of the batch for `seconds`; all
+    processes run their timed region together; best of `repeats`. (r02 ran the trajectories as OpenMP threads of one process:
+    OpenBLAS serialises concurrent callers on internal locks -- 599 accepted steps/s on one thread, 957 on sixteen -- while the
+    plain-loop back end scaled linearly, 81 per thread: scripts/cpu_scaling_probe.py, profiles/r03_cpu_scaling_probe.txt.)"""
     aff, quota = _granted_cpus()
     threads = int(os.environ.get("PNODE_CPU_THREADS", min(aff, quota) if quota else aff))
-    vf, tcs = problem_batch(max(threads, 1), 0, 1024)
-    tc = np.ascontiguousarray(np.stack(tcs, axis=1))
     path = os.path.join(ROOT, "oracle", "libpn_oracle_c.so")
+    vf, tcs = problem_batch(1, 0, 1024)
     if os.path.exists(path):
-        lib = C.CDLL(path)
-        dp = C.POINTER(C.c_double)
-        lib.pnoc_bench_brusselator.restype = C.c_double
-        lib.pnoc_bench_brusselator.argtypes = [C.c_int, C.c_int, C.c_int, dp, C.c_double, C.c_double, C.c_double, C.c_int,
-                                               C.POINTER(C.c_long), C.POINTER(C.c_long)]
-        lib.pnoc_use_lapack.argtypes = [C.c_char_p]
-        backend = "plain loops"
-        try:
-            import scipy
-
-            hits = glob.glob(os.path.join(os.path.dirname(scipy.__file__), "..", "scipy.libs", "libscipy_openblas*.so"))
-            if hits and lib.pnoc_use_lapack(hits[0].encode()) == 1:
-                backend = "LAPACK dgeqrf + BLAS dgemm/dtrsm (scipy's OpenBLAS, 1 BLAS thread per OpenMP thread)"
-        except ImportError:
-            pass
-
-        def run(nthreads, secs):
-            acc, att = C.c_long(), C.c_long()
-            el = lib.pnoc_bench_brusselator(N_SPATIAL, NU, nthreads, tc.ctypes.data_as(dp), TOL, DT0, secs, nthreads,
-                                            C.byref(acc), C.byref(att))
-            return acc.value / el, att.value / el, el
-
-        run(threads, 1.0)  # warm-up
-        runs = [run(threads, seconds) for _ in range(repeats)]
+        allowed = sorted(os.sched_getaffinity(0))
+        stride = max(1, len(allowed) // threads)
+        cores = allowed[::stride][:threads]  # distinct cores spread over the mask (not SMT siblings where the mask allows)
+        single = _cpu_workers(1, seconds, "lapack", cores[:1])[0]
+        runs = []
+        for _ in range(repeats):
+            res = _cpu_workers(threads, seconds, "lapack", cores)
+            runs.append((sum(r["accepted"] / r["seconds"] for r in res), sum(r["attempted"] / r["seconds"] for r in res)))
         best = max(runs)
-        single = run(1, seconds)
+        single_v = single["accepted"] / single["seconds"]
         return {"value": best[0], "unit": "accepted steps/s", "cores": int(threads), "kind": "port",
-                "single_core_value": single[0],
-                "sample": f"oracle/pn_oracle_c.c, {backend}; OpenMP, one trajectory per thread, {threads} trajectories of the same "
-                          f"batch for {seconds:.0f}s each: best of {repeats} runs after a warm-up "
+                "single_core_value": single_v, "per_core_value_all_busy": best[0] / threads,
+                "sample": f"oracle/pn_oracle_c.c, {single['backend']}; {threads} processes, one trajectory of the same batch and one "
+                          f"pinned core each, {seconds:.0f}s each, started together: best of {repeats} runs after a warm-up "
                           f"({', '.join(f'{r[0]:.0f}' for r in runs)} accepted steps/s; {best[1]:.0f} attempted steps/s); "
-                          f"{best[0] / threads:.1f} steps/s per core with all cores busy, {single[0]:.1f} on one core alone; "
+                          f"{best[0] / threads:.1f} steps/s per core with all cores busy, {single_v:.1f} on one core alone; "
                           f"affinity mask {aff} cpus, cgroup quota {quota}, os.cpu_count() {os.cpu_count()}"}
     # fallback: NumPy oracle, single process
     import pn_oracle as po
@@ -160,6 +167,61 @@ def cpu_baseline(seconds=5.0, repeats=3):
             "sample": f"NumPy oracle (oracle/pn_oracle.py), 1 trajectory, {accepted} accepted steps in {el:.1f}s"}
 
 
+def whole_solve(model, B, device_controller, device):
+    """One whole adaptive solve of the headline batch, t in [0, 10] (the reference's interval, ivps.py:124-156), through the public
+    API: accepted / attempted steps and wall time including the controller and the checkpoint interpolation."""
+    from probdiffeq_hip import ivpsolve, ivpsolvers
+    from probdiffeq_hip.impl import impl
+
+    vf, tcs = problem_batch(B)
+    impl.select(model, ode_shape=(vf.d,))
+    corr = ivpsolvers.correction_ts1() if model == "dense" else ivpsolvers.correction_ts0()
+    solver = ivpsolvers.solver_dynamic(ivpsolvers.strategy_filter(ivpsolvers.prior_ibm(NU), corr))
+    asolver = ivpsolve.adaptive(solver, atol=TOL, rtol=TOL)
+    init = solver.initial_condition(tcs, 1.0)
+    save_at = np.linspace(0.0, 10.0, 5)
+    tic = time.perf_counter()
+    sol = ivpsolve.solve_adaptive_save_at(vf, init, save_at=save_at, dt0=DT0, adaptive_solver=asolver, device=device,
+                                          device_controller=device_controller)
+    el = time.perf_counter() - tic
+    acc, att = int(np.sum(sol.num_steps[..., -1])), int(np.sum(sol.num_attempts))
+    return {"accepted": acc, "attempted": att, "seconds": el, "accepted_steps_per_s": acc / el, "finite": bool(np.all(np.isfinite(sol.u)))}
+
+
+def extras(args, batch, loop, active, dense, device_ctl, device):
+    """Legs outside the timed region (N = 1): the same batch stepped with the HOST controller (the north star's division of
+    labour: one round trip per attempt), whole solves with both controllers (the figure that does not depend on the window of
+    attempts), and the isotropic EKF0 nu = 3 line of SURVEY 8(d) with its fraction of the HBM roofline."""
+    out = {}
+    if device_ctl:
+        k = min(args.steps, 20)
+        t0 = time.perf_counter()
+        for _ in range(k):
+            loop.attempt(active)
+        out["host_controller_ms_per_step"] = 1e3 * (time.perf_counter() - t0) / k
+    batch.close()
+    B = args.batch
+    ws = {}
+    for name, dev in (("device_controller", True), ("host_controller", False)):
+        ws[name] = whole_solve("dense" if dense else "isotropic", B, dev, device)
+    out["whole_solve"] = {"t_span": [0.0, 10.0], "save_at_points": 5, **ws}
+    if dense:
+        n = NU + 1
+        d = 2 * N_SPATIAL
+        iso = {}
+        for name, dev in (("device_controller", True), ("host_controller", False)):
+            whole_solve("isotropic", B, dev, device)  # warm-up (code paging)
+            r = whole_solve("isotropic", B, dev, device)
+            byts = 2 * 8 * (n * d + n * n)  # SURVEY 8(d): state in + out per attempted step
+            r["algorithmic_bytes_per_step"] = byts
+            r["hbm_GBps"] = r["attempted"] / r["seconds"] * byts / 1e9
+            r["hbm_frac"] = r["hbm_GBps"] / HBM_PEAK_GBS
+            iso[name] = r
+        out["isotropic_ekf0_nu3"] = {"workload": f"Brusselator N=32 (d=64), nu=3, isotropic EKF0 (the reference's own model for this PDE), "
+                                                 f"filter, dynamic, tol 1e-6, batch {B}, whole solve t in [0, 10]", **iso}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -173,6 +235,9 @@ def main():
                     help="time update of the MFMA path: the library's default (one launch, overlapping 64-row passes) or the "
                          "two-launch kernels with 32-row passes (A/B comparison)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the legs outside the timed region (N = 1 only): host-controller attempts, whole solves of the "
+                         "headline batch with both controllers, the isotropic EKF0 line")
     ap.add_argument("--controller", default="device", choices=["device", "host"],
                     help="device: accept/reject + PI law in a controller kernel between the attempts, the timed steps are enqueued "
                          "back to back with one synchronisation at the end (pnode_advance_device); host: one round trip per step")
@@ -276,7 +341,9 @@ def main():
         accepted = int(batch.read_time()[1].sum()) - acc0
         dev_ms = batch.last_step_ms()  # HIP events around the K attempts on the handle's stream
         if dense:
-            phase = np.array(batch.last_phase_ms()) * args.steps  # events of the last attempt (every attempt launches the same kernels)
+            ph, cnt = batch.phase_ms_mean()  # HIP events around every kernel of EVERY timed attempt, on the handle's stream
+            assert cnt == args.steps
+            phase = np.array(ph) * args.steps
     else:
         for _ in range(args.warmup):
             loop.attempt(active)
@@ -359,7 +426,7 @@ def main():
         }
         if dense:
             lq_ms = phase[2] / K
-            flops = algorithmic_flops_lq(D) * B
+            flops = algorithmic_flops_lq(D, d) * B
             achieved = flops / (lq_ms * 1e-3) / 1e12
             # the north star also asks for the fraction of the HBM roofline: whole step (all dense kernels), algorithmic bytes
             # (state factor read + written once, 2 * 8 * D^2 per trajectory) and the bytes the PMC pass measured
@@ -376,10 +443,14 @@ def main():
                 hbm["measured_frac"] = hbm["measured_GBps"] / HBM_PEAK_GBS
             out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "hbm": hbm,
                                "frac": achieved / FP64_PEAK_TFLOPS, "traffic": measured_traffic("dense_lq4_mfma_kernel" if one_launch_lq else "dense_lq2_mfma_kernel", B),
-                               "traffic_source": "profiles/r02_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
+                               "traffic_source": "profiles/" + next((n for n in PMC_SUMMARIES if os.path.exists(os.path.join(ROOT, "profiles", n))), "-")
+                                                 + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command, separate passes; not re-measured in this run)",
                                "kernel": "dense_lq4_mfma_kernel<16,4> (one launch)" if one_launch_lq else
                                          "dense_lq2_mfma_kernel<16,true> + <16,false> (one LQ, two launches)",
                                "algorithmic_flops_per_launch": flops,
+                               "algorithmic_flops_note": "2 D^2 (D - d) per trajectory: LQ on the D - d columns of the rank-deficient state "
+                                                         "factor (r02 counted 2 D^3 for the LQ on D columns); time = mean over the K timed attempts",
+                               "frac_r02_count": 2.0 * D**3 * B / (lq_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                                "phase_ms": {"begin": phase[0] / K, "lq_input": phase[1] / K, "lq": phase[2] / K,
                                             "correct": phase[3] / K}}
         else:
@@ -388,6 +459,8 @@ def main():
             achieved = byts / (dev_ms / K * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "iso_step_kernel"}
+        if world == 1 and not args.no_extras and args.diag_fixed_dt == 0.0:
+            out.update(extras(args, batch, loop, active, dense, device_ctl, local))
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

@@ -170,6 +170,10 @@ struct pnode_batch {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   PhaseEvents phase{};
   bool phase_timing = false;
+  std::vector<PhaseEvents> phase_pool;  // one set per round of pnode_advance_device, so that every attempt's phases are timed
+  double phase_sum[4] = {0.0, 0.0, 0.0, 0.0};
+  int64_t phase_count = 0;
+  const PhaseEvents* phase_last = nullptr;  // events of the most recent attempt (the handle's own set or one of the pool)
   IsoView iso{};
   DenseView dn{};
   IwpConst* dK = nullptr;
@@ -224,6 +228,9 @@ int pnode_destroy(pnode_batch* h) {
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   for (auto& e : h->phase.ev)
     if (e) (void)hipEventDestroy(e);
+  for (auto& pe : h->phase_pool)
+    for (auto& e : pe.ev)
+      if (e) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return PNODE_OK;
@@ -502,15 +509,16 @@ static int check_fault(pnode_batch* h) {
   return fail(PNODE_EDEVICE, msg);
 }
 
-static void enqueue_step(pnode_batch* h, const StepArg* dargs, double* errnorm = nullptr) {
+static void enqueue_step(pnode_batch* h, const StepArg* dargs, double* errnorm = nullptr, const PhaseEvents* events = nullptr) {
   h->stepped = true;
   if (h->dense) {
+    const PhaseEvents* ev = h->phase_timing ? (events ? events : &h->phase) : nullptr;
     if (errnorm) {  // error norms to device memory (device-resident controller) instead of the pinned host buffer
       DenseView v = h->dn;
       v.errnorm = errnorm;
-      dense_launch_step(v, dargs, h->dK, h->stream, h->phase_timing ? &h->phase : nullptr);
+      dense_launch_step(v, dargs, h->dK, h->stream, ev);
     } else {
-      dense_launch_step(h->dn, dargs, h->dK, h->stream, h->phase_timing ? &h->phase : nullptr);
+      dense_launch_step(h->dn, dargs, h->dK, h->stream, ev);
     }
   } else if (errnorm) {
     IsoView v = h->iso;
@@ -529,14 +537,32 @@ static int advance_rounds_device(pnode_batch* h, TrajCtl* hCtl, const ControlPar
   HIP_TRY(hipMemcpyAsync(h->dCtl, hCtl, B * sizeof(TrajCtl), hipMemcpyHostToDevice, h->stream));
   hipLaunchKernelGGL(dense_ctl_kernel, dim3(blocks), dim3(256), 0, h->stream, h->dCtl, h->dArgs, h->dErr, cp, int(B), 1);
   if (h->step_timing) HIP_TRY(hipEventRecord(h->ev0, h->stream));
+  const bool per_round = h->dense && h->phase_timing;
+  if (per_round)
+    while (h->phase_pool.size() < size_t(rounds)) {
+      PhaseEvents pe{};
+      for (auto& e : pe.ev) HIP_TRY(hipEventCreate(&e));
+      h->phase_pool.push_back(pe);
+    }
   for (int r = 0; r < rounds; ++r) {
-    enqueue_step(h, h->dArgs, h->dErr);
+    enqueue_step(h, h->dArgs, h->dErr, per_round ? &h->phase_pool[size_t(r)] : nullptr);
     hipLaunchKernelGGL(dense_ctl_kernel, dim3(blocks), dim3(256), 0, h->stream, h->dCtl, h->dArgs, h->dErr, cp, int(B), 0);
   }
   if (h->step_timing) HIP_TRY(hipEventRecord(h->ev1, h->stream));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(hCtl, h->dCtl, B * sizeof(TrajCtl), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
+  if (per_round) {  // phase durations of EVERY attempt of this call (pnode_phase_ms_mean)
+    for (double& x : h->phase_sum) x = 0.0;
+    h->phase_count = rounds;
+    for (int r = 0; r < rounds; ++r)
+      for (int i = 0; i < 4; ++i) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, h->phase_pool[size_t(r)].ev[i], h->phase_pool[size_t(r)].ev[i + 1]));
+        h->phase_sum[i] += ms;
+      }
+    h->phase_last = &h->phase_pool[size_t(rounds - 1)];  // pnode_last_phase_ms keeps meaning "the last attempt"
+  }
   return check_fault(h);
 }
 
@@ -560,6 +586,7 @@ int pnode_attempt_step(pnode_batch* h, const double* dt, const uint8_t* active, 
   // zero-copy hand-over: the kernels read StepArg[B] from and write err_norm[B] to pinned host memory, so a step
   // costs the launches plus one stream synchronisation (no hipMemcpy calls on the critical path)
   if (h->step_timing) HIP_TRY(hipEventRecord(h->ev0, h->stream));
+  h->phase_last = nullptr;
   enqueue_step(h, h->zArgs);
   if (h->dense && h->dn.fixedpoint) {
     for (size_t b = 0; b < B; ++b) {
@@ -1276,7 +1303,17 @@ int pnode_set_phase_timing(pnode_batch* h, int32_t enabled) {
 int pnode_last_phase_ms(pnode_batch* h, float* ms_out) {
   if (!h || !ms_out) return fail(PNODE_EINVAL, "null argument");
   if (!h->dense || !h->phase_timing) return fail(PNODE_ESTATE, "phase timing is available for the dense model after set_phase_timing(1)");
-  for (int i = 0; i < 4; ++i) HIP_TRY(hipEventElapsedTime(ms_out + i, h->phase.ev[i], h->phase.ev[i + 1]));
+  const PhaseEvents& pe = h->phase_last ? *h->phase_last : h->phase;
+  for (int i = 0; i < 4; ++i) HIP_TRY(hipEventElapsedTime(ms_out + i, pe.ev[i], pe.ev[i + 1]));
+  return PNODE_OK;
+}
+
+int pnode_phase_ms_mean(pnode_batch* h, float* ms_out, int64_t* attempts_out) {
+  if (!h || !ms_out) return fail(PNODE_EINVAL, "null argument");
+  if (!h->dense || !h->phase_timing || h->phase_count <= 0)
+    return fail(PNODE_ESTATE, "needs the dense model, pnode_set_phase_timing(h, 1) and a pnode_advance_device call since");
+  for (int i = 0; i < 4; ++i) ms_out[i] = float(h->phase_sum[i] / double(h->phase_count));
+  if (attempts_out) *attempts_out = h->phase_count;
   return PNODE_OK;
 }
 

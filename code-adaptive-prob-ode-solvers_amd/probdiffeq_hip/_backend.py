@@ -24,7 +24,7 @@ SYMBOLS = (
     "pnode_set_tolerances pnode_attempt_step pnode_user_extrapolate pnode_user_set_vf pnode_commit pnode_interpolate pnode_checkpoint_at_step "
     "pnode_solve_fixed_grid pnode_solve_adaptive_save_at pnode_solve_adaptive_save_at_device pnode_read_mean pnode_read_time pnode_read_output_scale pnode_read_factor "
     "pnode_read_checkpoint_means pnode_read_checkpoint_factors pnode_smooth_checkpoint_means pnode_last_step_ms pnode_set_phase_timing "
-    "pnode_last_phase_ms pnode_set_generic_path pnode_stream pnode_advance_device pnode_debug_set_lq_spin_limit"
+    "pnode_last_phase_ms pnode_set_generic_path pnode_stream pnode_advance_device pnode_debug_set_lq_spin_limit pnode_phase_ms_mean"
 ).split()
 
 
@@ -116,6 +116,7 @@ def load_library():
     lib.pnode_set_generic_path.argtypes = [vp, C.c_int32]
     lib.pnode_debug_set_lq_spin_limit.argtypes = [vp, C.c_int32]
     lib.pnode_last_phase_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.pnode_phase_ms_mean.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int64)]
     lib.pnode_stream.argtypes = [vp]
     lib.pnode_offgrid_means.argtypes = [vp, i32p, dp, C.c_int32, dp, dp, dp, i32p, u8p, dp]
     lib.pnode_sample_checkpoints.argtypes = [vp, i32p, C.c_int32, dp, dp]
@@ -391,6 +392,12 @@ class Batch:
         ms = (C.c_float * 4)()
         _check(self._lib.pnode_last_phase_ms(self._h, ms))
         return [float(x) for x in ms]
+
+    def phase_ms_mean(self):
+        """(ms[4], attempts): phase durations averaged over every attempt of the last advance_device call."""
+        ms, cnt = (C.c_float * 4)(), C.c_int64()
+        _check(self._lib.pnode_phase_ms_mean(self._h, ms, C.byref(cnt)))
+        return [float(x) for x in ms], int(cnt.value)
 
     def last_step_ms(self):
         ms = C.c_float()

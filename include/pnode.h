@@ -227,6 +227,9 @@ int pnode_debug_set_lq_spin_limit(pnode_batch* h, int32_t polls);
  * read the durations of the last attempt, ms_out[4] = {begin, lq_input, lq, correct}. */
 int pnode_set_phase_timing(pnode_batch* h, int32_t enabled);
 int pnode_last_phase_ms(pnode_batch* h, float* ms_out);
+/* The same four durations averaged over EVERY attempt of the most recent pnode_advance_device call (one set of HIP events per
+ * round on the handle's stream); attempts_out (may be null) receives the number of attempts averaged. */
+int pnode_phase_ms_mean(pnode_batch* h, float* ms_out, int64_t* attempts_out);
 /* Raw stream handle (hipStream_t) for callers that need to order their own work after ours. */
 void* pnode_stream(pnode_batch* h);
 /* Device-resident controller as a building block (/root/reference/src/odecheckpts/ivpsolvers.py:52-53 is the
