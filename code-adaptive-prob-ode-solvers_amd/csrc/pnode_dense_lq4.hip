@@ -63,7 +63,8 @@ __global__ __launch_bounds__(512) void dense_lq4_mfma_kernel(const DenseView v, 
   constexpr int D = 16 * DT, d = 16 * DD, NBLK = DT / 4;
   // Mt = (Abar P^-1 (x) I) Ls has the D - d columns of the rank-deficient state factor (pnode_common.hpp), padded to DC tiles
   constexpr int DC = mfma_col_tiles(DT, DD), WC = 16 * DC;
-  constexpr int LDV = WC + 1;  // odd: the A-operand reads of the G phase (16 rows x 4 column groups) spread over the banks
+  constexpr int LDV = WC + 1;
+  constexpr int DCT = 2 * DD;  // 16-column tiles of the T scratch (columns < 2d)  // odd: the A-operand reads of the G phase (16 rows x 4 column groups) spread over the banks
   __shared__ double Vx[4 * kNB * LDV];
   __shared__ double TfS[4 * kNB * kNB];
   __shared__ double sclS[4 * kNB];
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(512) void dense_lq4_mfma_kernel(const DenseView v, 
     int n = 0;
     while (__builtin_amdgcn_readfirstlane(*f) < target) {
       __builtin_amdgcn_s_sleep(2);
-      if ((++n & 255) == 0 && timed_out(n, 0, target)) break;
+      if (((++n & 255) == 0 || n > spin_limit) && timed_out(n, 0, target)) break;
     }
     asm volatile("" ::: "memory");
   };
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(512) void dense_lq4_mfma_kernel(const DenseView v, 
       const int mine = (lane < 8) ? *(volatile lds_int*)&doneS[8 * k + lane] : 0x7fffffff;
       if (!__any(mine < G)) break;
       __builtin_amdgcn_s_sleep(2);
-      if ((++n & 255) == 0 && timed_out(n, 1, G)) break;
+      if (((++n & 255) == 0 || n > spin_limit) && timed_out(n, 1, G)) break;
     }
     asm volatile("" ::: "memory");
   };
@@ -221,18 +222,17 @@ __global__ __launch_bounds__(512) void dense_lq4_mfma_kernel(const DenseView v, 
     const int j0 = kNB * st_, cp = 64 * pass + kNB * k;
     double4_t tv;
     apply_panel_to_strip_pipelined<DC, LDV>(X, Vx + k * kNB * LDV, TfS + k * kNB * kNB, sclS + k * kNB, t0_tile(j0, cp, r, g), tv, r, g);
-    tv = transpose_groups(tv);  // lane (r, g): columns cp + 4 g .. cp + 4 g + 3 of row j0 + r
     const bool direct = is_direct(pass);
-    const double osc = direct ? pS[(j0 + r) / d] : 1.0;
-    const double2 lo2{osc * tv[0], osc * tv[1]}, hi2{osc * tv[2], osc * tv[3]};
     if (direct) {  // strip order of the state factor (column c of L^- is column c - d of Ls): two pairs per lane, 16 lanes of a pair contiguous
+      tv = transpose_groups(tv);  // lane (r, g): columns cp + 4 g .. cp + 4 g + 3 of row j0 + r
+      const double osc = pS[(j0 + r) / d];
       double* base = Ldst + tiled_index<DC>(j0 + r, cp + 4 * g - d);
-      *reinterpret_cast<double2*>(base) = lo2;
-      *reinterpret_cast<double2*>(base + 128) = hi2;  // next pair: + 64 lanes x 2 doubles
-    } else {
-      double* Trow = T + size_t(j0 + r) * D + cp + 4 * g;
-      *reinterpret_cast<double2*>(Trow) = lo2;
-      *reinterpret_cast<double2*>(Trow + 2) = hi2;
+      *reinterpret_cast<double2*>(base) = double2{osc * tv[0], osc * tv[1]};
+      *reinterpret_cast<double2*>(base + 128) = double2{osc * tv[2], osc * tv[3]};  // next pair: + 64 lanes x 2 doubles
+    } else {  // T scratch: the C/D fragment as it is (lane (r, g): columns cp + g + 4 q), tile-aligned strip order (tiledpi_index)
+      double* base = T + tiledpi_index<DCT>(j0 + r, cp + g);
+      *reinterpret_cast<double2*>(base) = double2{tv[0], tv[1]};
+      *reinterpret_cast<double2*>(base + 128) = double2{tv[2], tv[3]};
     }
     st.mark(2);
   };
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(512) void dense_lq4_mfma_kernel(const DenseView v, 
           const int mine = (lane < 8) ? *(volatile lds_int*)&trajS[lane] : 0x7fffffff;
           if (!__any(mine < it - 1)) break;
           __builtin_amdgcn_s_sleep(4);
-          if ((++n & 255) == 0 && timed_out(n, 2, it - 1)) break;
+          if (((++n & 255) == 0 || n > spin_limit) && timed_out(n, 2, it - 1)) break;
         }
         asm volatile("" ::: "memory");
       }
@@ -362,18 +362,22 @@ __global__ __launch_bounds__(512) void dense_lq4_mfma_kernel(const DenseView v, 
         lds_done();
         if (lane == 0) *(volatile lds_int*)&pubS[j] = base + P + 1;
         {
-          // diagonal block of T: lane (r, g) writes columns 4g .. 4g+3 of row r (zeros above the diagonal)
-          double o4[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) o4[q] = (4 * g + q <= r) ? tpp_row[4 * g + q] : 0.0;  // (the sweep leaves the upper triangle unwritten)
+          // diagonal block of T (zeros above the diagonal; the sweep leaves the upper triangle of tpp unwritten)
           const int row = cp + r;
-          const bool direct = is_direct(P);
-          const double osc = direct ? pS[row / d] : 1.0;
+          if (is_direct(P)) {  // state factor: lane (r, g) writes columns 4g .. 4g+3 of row r
+            const double osc = pS[row / d];
 #pragma unroll
-          for (int q = 0; q < 4; q += 2) {
-            const double2 t2{osc * o4[q], osc * o4[q + 1]};
-            double* dstp = direct ? Ldst + tiled_index<DC>(row, cp + 4 * g + q - d) : T + size_t(row) * D + cp + 4 * g + q;
-            *reinterpret_cast<double2*>(dstp) = t2;  // (4 g + q is even: the pair is contiguous in both layouts)
+            for (int q = 0; q < 4; q += 2) {
+              const double2 t2{osc * ((4 * g + q <= r) ? tpp_row[4 * g + q] : 0.0), osc * ((4 * g + q + 1 <= r) ? tpp_row[4 * g + q + 1] : 0.0)};
+              *reinterpret_cast<double2*>(Ldst + tiled_index<DC>(row, cp + 4 * g + q - d)) = t2;  // (4 g + q is even: the pair is contiguous)
+            }
+          } else {  // T scratch: lane (r, g) writes columns g + 4q
+            double o4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o4[q] = (g + 4 * q <= r) ? tpp_row[g + 4 * q] : 0.0;
+            double* base = T + tiledpi_index<DCT>(row, cp + g);
+            *reinterpret_cast<double2*>(base) = double2{o4[0], o4[1]};
+            *reinterpret_cast<double2*>(base + 128) = double2{o4[2], o4[3]};
           }
         }
         st.mark(5);

@@ -150,6 +150,7 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
   constexpr int D = 16 * DT;
   constexpr int DC = mfma_col_tiles(DT, DD), WC = 16 * DC;  // columns of Mt: the rank-deficient state factor (pnode_common.hpp)
   constexpr int LDV = WC + 1;  // 2*LDV = 2 (mod 64) dwords: conflict-free A-operand reads in the G phase
+  constexpr int DCT = 2 * DD;  // 16-column tiles of the T scratch (columns < 2d), tile-aligned strip order (tiledpi_index)
   __shared__ double Vx[2 * kNB * LDV];
   __shared__ double TppS[2 * kNB * kNB];
   __shared__ double TfS[2 * kNB * kNB];
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
         for (int q = 0; q < 4; ++q) {
           const int row = c0 + kNB + r, col = c0 + g + 4 * q;
           if (direct) Ldst[tiled_index<DC>(row, col - d)] = pS[row / d] * (t0v[q] - w4[q]);
-          else T[size_t(row) * D + col] = t0v[q] - w4[q];
+          else T[tiledpi_index<DCT>(row, col)] = t0v[q] - w4[q];
         }
       }
       w4 = w4 * sc;
@@ -306,13 +307,12 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
     {
       const int i = tid >> 4, j = tid & 15;
       if (j <= i) {
-        const size_t oa = size_t(c0 + i) * D + c0 + j, ob = size_t(c0 + kNB + i) * D + c0 + kNB + j;
-        if (direct) {
+          if (direct) {
           Ldst[tiled_index<DC>(c0 + i, c0 + j - d)] = pS[(c0 + i) / d] * psA.Tpp[i * kNB + j];
           Ldst[tiled_index<DC>(c0 + kNB + i, c0 + kNB + j - d)] = pS[(c0 + kNB + i) / d] * psB.Tpp[i * kNB + j];
         } else {
-          T[oa] = psA.Tpp[i * kNB + j];
-          T[ob] = psB.Tpp[i * kNB + j];
+          T[tiledpi_index<DCT>(c0 + i, c0 + j)] = psA.Tpp[i * kNB + j];
+          T[tiledpi_index<DCT>(c0 + kNB + i, c0 + kNB + j)] = psB.Tpp[i * kNB + j];
         }
       }
     }
@@ -363,11 +363,10 @@ __global__ __launch_bounds__(256, 2) void dense_lq2_mfma_kernel(DenseView v, con
           Ldst[tiled_index<DC>(j0 + r, c0 + kNB + g + 4 * q - d)] = osc * tb[q];
         }
       } else {
-        double* Trow = T + size_t(j0 + r) * D + c0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          Trow[g + 4 * q] = ta[q];
-          Trow[kNB + g + 4 * q] = tb[q];
+          T[tiledpi_index<DCT>(j0 + r, c0 + g + 4 * q)] = ta[q];
+          T[tiledpi_index<DCT>(j0 + r, c0 + kNB + g + 4 * q)] = tb[q];
         }
       }
     };
@@ -591,22 +590,304 @@ __global__ __launch_bounds__(256) void dense_begin_mfma_kernel(DenseView v, cons
   if (tid == 0) v.sig_new[b] = v.dynamic ? sigma_hat : v.sigma[size_t(arg.src) * sB + b];
 }
 
-// Second half of the measurement update: every 16-row strip of L^- = diag(p) T, first 2d columns, is rotated by the
-// reflectors of F (d / 16 panels, in LDS): X Q = [Y1 | Y2]. Y1 = L^- W^T feeds the mean, Y2 = L^- Q2 is the dense part of the
-// new rank-(D - d) state factor (columns 0 .. d-1 of Ls; the columns >= 2d of L^- were written by the LQ kernel as the columns
-// >= d of Ls, already scaled). Then (strip block 0: the rows of the zeroth derivative) the normalised error norm.
+// ---------------------------------------------------------------------------------------------------------------------
+// Measurement update of the MFMA path, by orthogonal transformations only (the reference's square-root correction: QR of
+// (H L^-)^T, strategy_filter + correction_ts1, /root/reference/experiments/1_van_der_pol/vdp.py:64-65):
+//   F = H L^- (d x 2d: L^- is lower triangular),  F = [C 0] Q^T by a blocked row-Householder LQ (S = C C^T is never formed),
+//   L^- Q = [Y1 | Y2 | columns >= 2d]:  gain K = Y1 C^-1, mean m = m^- - Y1 (C^-1 z), and [Y2 | columns >= 2d] is a factor of the
+//   updated covariance with D - d columns -- the observation is noise-free, the d directions of Y1 are known exactly afterwards.
+// Two kernels (r03; one until then, 0.31 ms at B = 1024: its serial first half left the matrix core to a second workgroup only):
+//   dense_gain_mfma_kernel   -- F, its LQ, C^-1 z. A chain of d pivots: latency. Almost no LDS (one panel), three workgroups per CU.
+//   dense_rotate_mfma_kernel -- every 16-row strip of L^- rotated by the reflector panels: matrix-core streaming, NY workgroups
+//                               per trajectory; the 16-column tiles in which a panel is structurally zero are skipped.
+// Hand-over through the F scratch (v.Ft, per trajectory): reflector rows [d][2d] in strip order, Tf [d/16][16][16], scl [d],
+// C^-1 z [2d] (zeros beyond d).
+// ---------------------------------------------------------------------------------------------------------------------
+
+// Panel p of the LQ of F = [p1 T21 - p0 J T11 | p1 T22] (T22 lower triangular) is non-zero in the 16-column tiles p .. DD - 1 of
+// the first half and DD .. DD + p of the second: the reflectors of row block p start at column 16 p, and a row of F ends at its
+// diagonal entry in T22 (no fill-in beyond: the earlier reflectors end earlier).
+template <int DD>
+constexpr bool panel_has_tile(int p, int t) { return (t >= p && t < DD) || (t >= DD && t <= DD + p); }
+
+// apply_panel_to_strip (pnode_mfma_common.hpp) for a strip and a panel whose columns are in the tile-aligned order of
+// tiledpi_index (register e = 4 a + q of lane group g: column 64 T + 16 a + 4 q + g), without a T0 part, restricted to the
+// tiles of panel P. LDS image of the panel: Vp[row][64 T + 16 g + e] = that register of lane (row, g).
+template <int DF, int LDV, int DD, int P>
+__device__ __forceinline__ void apply_panel_sparse(double (&X)[4 * DF], const double* __restrict__ Vp, const double* __restrict__ Tfp,
+                                                   const double* __restrict__ sclp, int r, int g) {
+  double4_t acc4[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) acc4[a] = double4_t{0.0, 0.0, 0.0, 0.0};
+  double4_t sc;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) sc[q] = sclp[g + 4 * q];
+#pragma unroll
+  for (int T = 0; T < DF / 4; ++T) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double* vrow = Vp + r * LDV + 64 * T + 16 * g + q;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+        if (panel_has_tile<DD>(P, 4 * T + a)) acc4[a] = MFMA64(vrow[4 * a], X[16 * T + 4 * a + q], acc4[a]);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keep the LDS operand loads of later super-tiles from being hoisted
+  }
+  const double4_t gsum = ((acc4[0] + acc4[1]) + (acc4[2] + acc4[3])) * sc;  // G = (X raw^T) diag(scl)
+  double4_t w4 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) w4 = MFMA64(Tfp[(4 * kk + g) * kNB + r], gsum[kk], w4);
+  w4 = w4 * sc;  // the update below multiplies by the unscaled rows
+  const int coff = 16 * (r & 3) + (r >> 2);
+#pragma unroll
+  for (int T = 0; T < DF / 4; ++T) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (panel_has_tile<DD>(P, 4 * T + j)) {
+        double4_t c4 = {X[16 * T + 4 * j], X[16 * T + 4 * j + 1], X[16 * T + 4 * j + 2], X[16 * T + 4 * j + 3]};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) c4 = MFMA64(-Vp[(4 * kk + g) * LDV + 64 * T + 4 * j + coff], w4[kk], c4);
+        X[16 * T + 4 * j] = c4[0];
+        X[16 * T + 4 * j + 1] = c4[1];
+        X[16 * T + 4 * j + 2] = c4[2];
+        X[16 * T + 4 * j + 3] = c4[3];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int DD, int P, int DF, int LDV>
+__device__ __forceinline__ void apply_all_panels(double (&X)[4 * DF], const double* __restrict__ Vp, const double* __restrict__ Tfp,
+                                                 const double* __restrict__ sclp, int r, int g) {
+  if constexpr (P < DD) {
+    apply_panel_sparse<DF, LDV, DD, P>(X, Vp + P * kNB * LDV, Tfp + P * kNB * kNB, sclp + P * kNB, r, g);
+    apply_all_panels<DD, P + 1, DF, LDV>(X, Vp, Tfp, sclp, r, g);
+  }
+}
+
+// Offsets (in doubles) into the per-trajectory F scratch
+template <int DD> struct GainScratch {
+  static constexpr int d = 16 * DD, W2 = 2 * d;
+  static constexpr int V = 0, Tf = d * W2, scl = Tf + DD * kNB * kNB, wz = scl + d, size = wz + W2;
+};
+
 template <int DT, int DD>
-__device__ __forceinline__ void strip_update_body(const DenseView& v, const StepArg& arg, const IwpConst& K, int b,
-                                                  const double* __restrict__ Vf, const double* __restrict__ TfF,
-                                                  const double* __restrict__ sclF, const double* __restrict__ tv, double* red) {
-  constexpr int D = 16 * DT, d = 16 * DD, W2 = 2 * d, LDF = W2 + 1, DF = W2 / 16, DC = mfma_col_tiles(DT, DD);
+__global__ __launch_bounds__(256, 2) void dense_gain_mfma_kernel(DenseView v, const StepArg* __restrict__ args,
+                                                                 const IwpConst* __restrict__ Kc) {
+  constexpr int D = 16 * DT, d = 16 * DD, W2 = 2 * d, LDF = W2 + 1, DF = W2 / 16, DCT = DF;
+  static_assert(DD <= 4, "one wavefront per 16-row strip of F; the pivot columns of a strip lie in the first super-tile");
+  static_assert(GainScratch<DD>::size <= d * D, "the F scratch holds the hand-over");
+  __shared__ double Vs[kNB * LDF];     // the panel being applied (unscaled reflector rows, pivot entries 1 / scl)
+  __shared__ double TfS[kNB * kNB];
+  __shared__ double sclS[kNB];
+  __shared__ double tpp[kNB * kNB];    // diagonal block of C of the sweeping wavefront
+  __shared__ double wz[W2];            // z, then C^-1 z block by block; zeros beyond d
+  const int b = blockIdx.x;
+  const StepArg arg = args[b];
+  if (!arg.active) return;
+  const IwpConst& K = *Kc;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // Strip w of F is owned by wavefront (w + blockIdx) mod 4: the workgroups that share a CU run in lockstep, and a sweep is a pure
+  // vector-ALU stream; with the same wavefront number sweeping in all of them, the sweeps would queue on ONE SIMD.
+  const int wv = ((tid >> 6) + 4 - (blockIdx.x & 3)) & 3;
+  const int r = lane & 15, g = lane >> 4;
+  double p[kMaxN], pinv[kMaxN];
+  precond_rt(v.n, arg.dt, K, p, pinv);
+  const double p0 = p[0], p1 = p[1];
+  const double* __restrict__ T = v.R + size_t(b) * D * D;  // tile-aligned strip order, columns < 2d (tiledpi_index)
+  const double* __restrict__ Jg = v.J + size_t(b) * d * d;
+  double* __restrict__ hand = v.Ft + size_t(b) * d * D;
+  for (int j = tid; j < W2; j += 256) wz[j] = j < d ? v.z[size_t(b) * d + j] : 0.0;
+  const bool owner = wv < DD;
+#ifdef PNODE_TIMING_BUILD
+  // diagnostic build only: cycle sums by phase per wavefront, written behind the LQ's stamps in the S scratch
+  unsigned long long ck_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long ck_prev = __builtin_amdgcn_s_memtime();
+#define CK_STAMP(slot)                                             \
+  do {                                                             \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();  \
+    ck_acc[slot] += now_ - ck_prev;                                \
+    ck_prev = now_;                                                \
+  } while (0)
+#else
+#define CK_STAMP(slot) \
+  do {                 \
+  } while (0)
+#endif
+  // ---- my strip of F in registers, plain strip order: X[16 T + e] = F[16 wv + r][64 T + 16 g + e]
+  //      F = p1 T[d + ., 0 : 2d] - p0 [J T11 | 0]   (the rows d .. 2d-1 of T end at their diagonal entry: zeros are stored there)
+  double X[4 * DF];
+  if (owner) {
+    // (addresses as ONE lane-dependent base + compile-time offsets: through tiledpi_index the compiler keeps a 64-bit address
+    // per load alive, 200 registers of addresses)
+    // plain column 64 T + 16 g + e of row 16 s + r sits at double index
+    //   (s 2 DCT + 8 T) 128 + 256 g + 2 r   +   (e >> 3) 128 + 32 (e & 3) + ((e >> 2) & 1)
+    const double* __restrict__ fbase = T + size_t(DD + wv) * (2 * DCT) * 128 + 256 * g + 2 * r;
+#pragma unroll
+    for (int T4 = 0; T4 < DF / 4; ++T4)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        // (the tiles beyond the diagonal tile of these rows are never written by the LQ: not read here)
+        const bool beyond = 4 * T4 + g > DD + wv;
+        X[16 * T4 + e] = beyond ? 0.0 : p1 * fbase[T4 * 1024 + (e >> 3) * 128 + 32 * (e & 3) + ((e >> 2) & 1)];
+      }
+    // - p0 (J T11)[16 wv + r][col]: the transposed product, so that the rows come out on the lanes: for the output registers
+    // 4 j .. 4 j + 3 (columns 16 g + 4 j + i; register i of the C/D fragment of lane group g is row m = g + 4 i of the product)
+    // lane r contributes, as row m = r of the A operand, column 16 (r & 3) + (r >> 2) + 4 j of T11; the B operand is my rows of J.
+    // T11[k = 4 s4 + g][that column] sits at   256 (r & 3) + 32 (r >> 2) + 2 g   +   ((s4 >> 2) 2 DCT + (j >> 1)) 128 + 8 (s4 & 3) + (j & 1)
+    double jrow[d / 4];
+#pragma unroll
+    for (int s4 = 0; s4 < d / 4; ++s4) jrow[s4] = -p0 * Jg[size_t(kNB * wv + r) * d + 4 * s4 + g];
+    const bool live = 16 * (r & 3) < d;  // (d = 32: the second half of the super-tile has no J T11 part)
+    const double* __restrict__ abase = T + 256 * (r & 3) + 32 * (r >> 2) + 2 * g;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      double aop[d / 4];
+#pragma unroll
+      for (int s4 = 0; s4 < d / 4; ++s4)  // all loads of a tile in flight together (zero above the diagonal of T11: the diagonal tiles store their zeros, the tiles beyond are never written)
+        aop[s4] = (live && (r & 3) <= (s4 >> 2)) ? abase[((s4 >> 2) * (2 * DCT) + (j >> 1)) * 128 + 8 * (s4 & 3) + (j & 1)] : 0.0;  // (tile r & 3 of row strip s4 >> 2)
+      double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s4 = 0; s4 < d / 4; ++s4) acc = MFMA64(aop[s4], jrow[s4], acc);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) X[4 * j + i] += acc[i];
+      __builtin_amdgcn_sched_barrier(0);  // (one tile's operands at a time: hoisted together they cost 128 registers)
+    }
+  }
+  CK_STAMP(0);
+  __syncthreads();  // wz
+  CK_STAMP(1);
+  // ---- blocked row-Householder LQ of F: wavefront w sweeps strip w in registers (pnode_lq_sweep.hpp), the panel goes through
+  //      ONE LDS buffer (two barriers per panel) and to the hand-over scratch
+#pragma unroll 1
+  for (int pnl = 0; pnl < DD; ++pnl) {
+    double tfrow[kNB], myscl = 0.0, rhs = 0.0;
+    const bool mine = owner && wv == pnl;
+    if (mine) {
+      // my columns before the panel are final entries of C (row block wv): their share of the forward substitution
+      //   rhs = z - C[rows, 0 : 16 wv] (C^-1 z)[0 : 16 wv]
+      // is taken here, then they leave the strip (the reflectors of this panel act on the columns >= 16 wv only)
+      double part = 0.0;
+      if (g < wv) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          part = fma(X[e], wz[16 * g + e], part);
+          X[e] = 0.0;
+        }
+      }
+      rhs = wz[kNB * wv + r] - sum_over_groups(part);
+#pragma unroll
+      for (int m = 0; m < kNB; ++m) tfrow[m] = 0.0;
+      pivot_sweep_inplace<0, DF>(X, tfrow, tpp + r * kNB, myscl, wv, g);
+      CK_STAMP(2);
+    }
+    __syncthreads();  // (A) every wavefront is done with the previous panel in Vs
+    CK_STAMP(3);
+    if (mine) {
+      double* __restrict__ hv = hand + GainScratch<DD>::V;
+#pragma unroll
+      for (int T4 = 0; T4 < DF / 4; ++T4)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          Vs[r * LDF + 64 * T4 + 16 * g + e] = X[16 * T4 + e];
+          if ((e & 1) == 0)  // hand-over: the strip in register order (pair pp of lane l at double2 index (wv 2 DF + pp) 64 + l)
+            reinterpret_cast<double2*>(hv)[(size_t(wv) * (2 * DF) + 8 * T4 + e / 2) * 64 + lane] = double2{X[16 * T4 + e], X[16 * T4 + e + 1]};
+        }
+      if (g == 0) {
+        sclS[r] = myscl;
+        hand[GainScratch<DD>::scl + kNB * wv + r] = myscl;
+#pragma unroll
+        for (int m = 0; m < kNB; ++m) {
+          TfS[r * kNB + m] = tfrow[m];
+          hand[GainScratch<DD>::Tf + wv * kNB * kNB + r * kNB + m] = tfrow[m];
+        }
+      }
+      // forward substitution with the diagonal block (lower triangular, row r in tpp): lane r of every group alike
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      double crow[kNB];
+#pragma unroll
+      for (int m = 0; m < kNB; ++m) crow[m] = (m <= r) ? tpp[r * kNB + m] : 0.0;  // (the sweep leaves the upper triangle unwritten)
+      double xsol = 0.0;
+      tri_forward16<0>(rhs, xsol, crow, r);
+      if (g == 0) {
+        wz[kNB * wv + r] = xsol;
+        hand[GainScratch<DD>::wz + kNB * wv + r] = xsol;
+      }
+      CK_STAMP(4);
+    }
+    __syncthreads();  // (B) the panel is in Vs
+    CK_STAMP(5);
+    if (owner && wv > pnl) {
+      double4_t unused;
+      apply_panel_to_strip<DF, LDF>(X, Vs, TfS, sclS, double4_t{0.0, 0.0, 0.0, 0.0}, unused, r, g);
+      CK_STAMP(6);
+    }
+  }
+  for (int j = d + tid; j < W2; j += 256) hand[GainScratch<DD>::wz + j] = 0.0;
+#ifdef PNODE_TIMING_BUILD
+  if (lane == 0) {
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(v.S + size_t(b) * d * d) + 64 + 8 * wv;
+    for (int i = 0; i < 8; ++i) dbg[i] = ck_acc[i];
+  }
+#endif
+}
+
+// Rotation of the strips of L^- = diag(p) T (first 2d columns) by the reflector panels of F: X Q = [Y1 | Y2]. Y1 = L^- W^T feeds
+// the mean, Y2 = L^- Q2 becomes the dense part of the new rank-(D - d) state factor (its columns 0 .. d-1, in the order the
+// registers hold them: the column order of a factor is immaterial); the columns >= 2d of L^- were written by the LQ kernel as
+// the columns >= d of Ls, already scaled. Workgroup y of NY takes the strips [DT / NY * y, DT / NY * (y + 1)); workgroup 0, which
+// holds the rows of the zeroth derivative, forms the normalised error norm.
+template <int DT, int DD, int NY>
+__global__ __launch_bounds__(256, 2) void dense_rotate_mfma_kernel(DenseView v, const StepArg* __restrict__ args,
+                                                                   const IwpConst* __restrict__ Kc) {
+  constexpr int D = 16 * DT, d = 16 * DD, W2 = 2 * d, LDF = W2 + 1, DF = W2 / 16, DCT = DF, DC = mfma_col_tiles(DT, DD);
+  static_assert(DT % (4 * NY) == 0 && (DT / NY) * 16 >= d, "whole strips per wavefront; workgroup 0 covers the rows of u");
+  extern __shared__ double gbuf[];
+  double* Vf = gbuf;                      // [d][LDF]  reflector rows, columns in the tile-aligned order of the strips
+  double* TfF = Vf + d * LDF;             // [DD][16][16]
+  double* sclF = TfF + DD * kNB * kNB;    // [d]
+  double* tv = sclF + d;                  // [2d] C^-1 z in the same column order, zeros for the columns >= d
+  double* red = tv + W2;                  // [4]
+  const int b = blockIdx.x, y = blockIdx.y;
+  const StepArg arg = args[b];
+  if (!arg.active) return;
+  const IwpConst& K = *Kc;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
+  const double* __restrict__ hand = v.Ft + size_t(b) * d * D;
+  // ---- stage the hand-over: the reflector strips are in plain register order (register e of group g: column 64 T + 16 g + e);
+  //      in the LDS image the slot [64 T + 16 g' + e'] holds column 64 T + 16 (e' >> 2) + 4 (e' & 3) + g'
+  {
+    const double2* __restrict__ hv = reinterpret_cast<const double2*>(hand + GainScratch<DD>::V);
+    for (int idx = tid; idx < d * W2 / 2; idx += 256) {
+      const int l = idx & 63, pp = (idx >> 6) % (2 * DF), st = idx / (64 * 2 * DF);
+      const double2 t2 = hv[idx];
+      const int rr = l & 15, gs = l >> 4, T4 = pp >> 3, es = 2 * (pp & 7);  // plain order: columns 64 T + 16 gs + es, + 1
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int c = 16 * gs + es + h;  // column inside the super-tile
+        const int a = c >> 4, q = (c >> 2) & 3, gp = c & 3;
+        Vf[(kNB * st + rr) * LDF + 64 * T4 + 16 * gp + 4 * a + q] = h ? t2.y : t2.x;
+      }
+    }
+    for (int idx = tid; idx < DD * kNB * kNB; idx += 256) TfF[idx] = hand[GainScratch<DD>::Tf + idx];
+    for (int idx = tid; idx < d; idx += 256) sclF[idx] = hand[GainScratch<DD>::scl + idx];
+    for (int idx = tid; idx < W2; idx += 256) {  // slot idx = 64 T + 16 g' + e'
+      const int T4 = idx >> 6, gp = (idx >> 4) & 3, ep = idx & 15;
+      const int col = 64 * T4 + 16 * (ep >> 2) + 4 * (ep & 3) + gp;
+      tv[idx] = col < d ? hand[GainScratch<DD>::wz + col] : 0.0;
+    }
+  }
+  __syncthreads();
   const double* __restrict__ T = v.R + size_t(b) * D * D;
   const size_t sB = size_t(v.B);
   double* mdst = v.mean + (size_t(arg.dst) * sB + b) * D;
   double* __restrict__ Ln = v.U + (size_t(arg.dst) * sB + b) * D * D;
-  for (int st = wv; st < DT; st += 4) {
+  constexpr int SPW = DT / NY / 4;  // strips per wavefront
+#pragma unroll 1
+  for (int it = 0; it < SPW; ++it) {
+    const int st = (DT / NY) * y + wv + 4 * it;
     const int row = 16 * st + r;
     const int iblk = (16 * st) / d;
     double pr;
@@ -617,46 +898,38 @@ __device__ __forceinline__ void strip_update_body(const DenseView& v, const Step
 #pragma unroll
       for (int i = 1; i < kMaxN; ++i) pr = (i == iblk) ? p[i] : pr;
     }
-    // register strip in the HBM layout  X[16 T + 4 j + q] = p_r T[row][64 T + 16 g + 4 j + q]  (128 B per lane
-    // and super-tile); T's upper triangle is stored as zeros, so no predicate is needed
-    double X[W2 / 4];
-    const double* __restrict__ trow = T + size_t(row) * D + 16 * g;
+    // the strip of T in the order it was stored: 1 KB per load instruction
+    double X[4 * DF];
+    const double2* __restrict__ trow = reinterpret_cast<const double2*>(T) + size_t(st) * (2 * DCT) * 64 + lane;
 #pragma unroll
-    for (int T4 = 0; T4 < W2 / 64; ++T4)
-#pragma unroll
-      for (int e = 0; e < 16; e += 2) {
-        const double2 t2 = *reinterpret_cast<const double2*>(trow + 64 * T4 + e);
-        X[16 * T4 + e] = pr * t2.x;
-        X[16 * T4 + e + 1] = pr * t2.y;
-      }
-#pragma unroll
-    for (int pnl = 0; pnl < DD; ++pnl) {
-      double4_t unused;
-      apply_panel_to_strip<DF, LDF>(X, Vf + pnl * kNB * LDF, TfF + pnl * kNB * kNB, sclF + pnl * kNB, double4_t{0.0, 0.0, 0.0, 0.0},
-                                    unused, r, g);
+    for (int pp = 0; pp < 2 * DF; ++pp) {
+      const double2 t2 = trow[pp * 64];
+      const bool beyond = (pp >> 1) > st;  // tile 4 T + a = pp / 2 of a strip of the first 2d rows: never written by the LQ
+      X[2 * pp] = beyond ? 0.0 : pr * t2.x;
+      X[2 * pp + 1] = beyond ? 0.0 : pr * t2.y;
     }
-    // mean: m -= Y1 (C^-1 z); tv holds C^-1 z in its first d entries and zeros beyond
+    apply_all_panels<DD, 0, DF, LDF>(X, Vf, TfF, sclF, r, g);
+    // mean: m -= Y1 (C^-1 z)
     double mpart = 0.0;
 #pragma unroll
-    for (int T4 = 0; T4 < W2 / 64; ++T4)
+    for (int T4 = 0; T4 < DF / 4; ++T4)
 #pragma unroll
       for (int e = 0; e < 16; ++e) mpart = fma(X[16 * T4 + e], tv[64 * T4 + 16 * g + e], mpart);
     mpart += __shfl_xor(mpart, 16, kWave);
     mpart += __shfl_xor(mpart, 32, kWave);
     if (g == 0) mdst[row] -= mpart;
-    {
-      // Y2 = columns d .. 2d-1 of the rotated strip -> columns 0 .. d-1 of the state factor, in the register order of its strips
+    // Y2: the columns d .. 2d-1 -> columns 0 .. d-1 of the state factor (any order)
+    if constexpr (DD == 4) {  // the second super-tile as it stands
+      double2* __restrict__ lrow = reinterpret_cast<double2*>(Ln) + size_t(st) * (2 * DC) * 64 + lane;
 #pragma unroll
-      for (int T4 = 0; T4 < W2 / 64; ++T4)
+      for (int e = 0; e < 16; e += 2) lrow[(e / 2) * 64] = double2{X[16 + e], X[16 + e + 1]};
+    } else {  // d = 32: the tiles 2, 3 of the only super-tile (registers 8 .. 15 of every group) -> the 32 columns of the groups 0, 1
 #pragma unroll
-        for (int e = 0; e < 16; e += 2) {
-          const int col = 64 * T4 + 16 * g + e - d;
-          if (col >= 0) *reinterpret_cast<double2*>(Ln + tiled_index<DC>(row, col)) = double2{X[16 * T4 + e], X[16 * T4 + e + 1]};
-        }
+      for (int e = 8; e < 16; ++e) Ln[tiled_index<DC>(row, 16 * (g & 1) + (e - 8) + 8 * (g >> 1))] = X[e];
     }
   }
-  {
-    // error norm over u = m[0] (rows 0 .. d-1 were updated above)
+  if (y == 0) {
+    // error norm over u = m[0] (rows 0 .. d-1 were updated above by this workgroup)
     __syncthreads();
     const double atol = v.atol[b], rtol = v.rtol[b];
     double part = 0.0;
@@ -672,170 +945,6 @@ __device__ __forceinline__ void strip_update_body(const DenseView& v, const Step
       v.sigma[size_t(arg.dst) * sB + b] = v.sig_new[b];
     }
   }
-}
-
-// Measurement update, ONE kernel per trajectory, by orthogonal transformations only (the reference's square-root correction:
-// QR of (H L^-)^T, strategy_filter + correction_ts1, /root/reference/experiments/1_van_der_pol/vdp.py:64-65):
-//   F = H L^- (d x 2d: L^- is lower triangular),  F = [C 0] Q^T by a blocked row-Householder LQ (S = C C^T is never formed),
-//   L^- Q = [Y1 | Y2 | columns >= 2d]:  gain K = Y1 C^-1, mean m = m^- - Y1 (C^-1 z), and [Y2 | columns >= 2d] is a factor of the
-//   updated covariance with D - d columns -- the observation is noise-free, the d directions of Y1 are known exactly afterwards.
-// The panels of the LQ (wavefront p sweeps strip p of F in registers, pnode_lq_sweep.hpp) stay in LDS for the strips of L^-.
-template <int DT, int DD>
-__global__ __launch_bounds__(256, 2) void dense_correct_mfma_kernel(DenseView v, const StepArg* __restrict__ args,
-                                                              const IwpConst* __restrict__ Kc) {
-  constexpr int D = 16 * DT, d = 16 * DD, W2 = 2 * d, LD = d + 1, LDF = W2 + 1, DF = W2 / 16;
-  static_assert(DD <= 4, "one wavefront per 16-row strip of F; the pivot columns of a strip lie in the first super-tile");
-  // One LDS buffer, two lives: (1) J and T[0:d, 0:d] staged for the MFMA that forms F (2) F itself, d x 2d, whose strips become
-  // the reflector panels in place.
-  extern __shared__ double gbuf[];
-  double* Js = gbuf;            // [d][LD]      life 1
-  double* Ts = gbuf + d * LD;   // [d][LD]      life 1
-  double* Fl = gbuf;            // [d][LDF]     life 2: F, then the reflector rows (unscaled, pivot entries 1 / scl)
-  double* TfF = gbuf + 2 * d * LD;     // [DD][16][16]  compact-WY factors of the panels   (beyond both lives)
-  double* sclF = TfF + DD * kNB * kNB; // [d]
-  double* tpp = sclF + d;              // [16][16]  diagonal block of C of the sweeping wavefront
-  double* wz = tpp + kNB * kNB;        // [2d]  C^-1 z, zeros beyond d
-  double* red = wz + W2;               // [4]
-  const int b = blockIdx.x;
-  const StepArg arg = args[b];
-  if (!arg.active) return;
-  const IwpConst& K = *Kc;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int r = lane & 15, g = lane >> 4;
-#ifdef PNODE_TIMING_BUILD
-  // diagnostic build only: cycle sums by phase of wavefront 0, written behind the LQ's stamps in the S scratch
-  unsigned long long ck_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long ck_prev = __builtin_amdgcn_s_memtime();
-#define CK_STAMP(slot)                                             \
-  do {                                                             \
-    const unsigned long long now_ = __builtin_amdgcn_s_memtime();  \
-    ck_acc[slot] += now_ - ck_prev;                                \
-    ck_prev = now_;                                                \
-  } while (0)
-#else
-#define CK_STAMP(slot) \
-  do {                 \
-  } while (0)
-#endif
-  double p[kMaxN], pinv[kMaxN];
-  precond_rt(v.n, arg.dt, K, p, pinv);
-  const double p0 = p[0], p1 = p[1];
-  const double* __restrict__ T = v.R + size_t(b) * D * D;
-  const double* __restrict__ Jg = v.J + size_t(b) * d * d;
-  // ---- life 1: stage J and the lower-triangular T[0:d, 0:d] (coalesced), form F[:, 0:d] = p1 T[d:2d, 0:d] - p0 J T[0:d, 0:d]
-  for (int idx = tid; idx < d * d; idx += 256) {
-    const int a = idx / d, c = idx % d;
-    Js[a * LD + c] = -p0 * Jg[idx];
-    Ts[a * LD + c] = T[size_t(a) * D + c];  // (the upper part is stored as zeros)
-  }
-  for (int j = tid; j < W2; j += 256) wz[j] = j < d ? v.z[size_t(b) * d + j] : 0.0;
-  constexpr int NT = (DD * DD + 3) / 4;  // F1 tiles per wavefront
-  double4_t f1[NT];
-#pragma unroll
-  for (int it = 0; it < NT; ++it) {
-    const int tile = wv + 4 * it;
-    if (tile < DD * DD) {
-      const int ta = tile / DD, tc = tile % DD;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) f1[it][q] = p1 * T[size_t(d + 16 * ta + g + 4 * q) * D + 16 * tc + r];
-    }
-  }
-  __syncthreads();
-  CK_STAMP(0);
-#pragma unroll
-  for (int it = 0; it < NT; ++it) {
-    const int tile = wv + 4 * it;
-    if (tile < DD * DD) {
-      const int ta = tile / DD, tc = tile % DD;
-      double4_t acc = f1[it];
-#pragma unroll
-      for (int s = 0; s < d / 4; ++s) acc = MFMA64(Js[(16 * ta + r) * LD + 4 * s + g], Ts[(4 * s + g) * LD + 16 * tc + r], acc);
-      f1[it] = acc;
-    }
-  }
-  __syncthreads();  // everyone is done with J and T in LDS
-  CK_STAMP(1);
-  // ---- life 2: F in LDS; F[:, d:2d] = p1 T[d:2d, d:2d] (lower triangular block)
-#pragma unroll
-  for (int it = 0; it < NT; ++it) {
-    const int tile = wv + 4 * it;
-    if (tile < DD * DD) {
-      const int ta = tile / DD, tc = tile % DD;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) Fl[(16 * ta + g + 4 * q) * LDF + 16 * tc + r] = f1[it][q];
-    }
-  }
-  for (int idx = tid; idx < d * d; idx += 256) {
-    const int a = idx / d, c = idx % d;
-    Fl[a * LDF + d + c] = (c <= a) ? p1 * T[size_t(d + a) * D + d + c] : 0.0;
-  }
-  __syncthreads();
-  CK_STAMP(2);
-  // ---- blocked row-Householder LQ of F: wavefront w owns strip w (16 rows, all 2d columns) in registers
-  double X[4 * DF];
-  const bool owner = wv < DD;
-  if (owner) {
-#pragma unroll
-    for (int T4 = 0; T4 < DF / 4; ++T4)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) X[16 * T4 + e] = Fl[(kNB * wv + r) * LDF + 64 * T4 + 16 * g + e];
-  }
-  CK_STAMP(3);
-#pragma unroll 1
-  for (int pnl = 0; pnl < DD; ++pnl) {
-    if (owner && wv == pnl) {
-      // my columns before the panel are final entries of C (row block wv): their share of the forward substitution
-      //   rhs = z - C[rows, 0 : 16 wv] (C^-1 z)[0 : 16 wv]
-      // is taken here, then they leave the strip (the reflectors of this panel act on the columns >= 16 wv only)
-      double part = 0.0;
-      if (g < wv) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          part = fma(X[e], wz[16 * g + e], part);
-          X[e] = 0.0;
-        }
-      }
-      double rhs = wz[kNB * wv + r] - sum_over_groups(part);
-      double tfrow[kNB], myscl = 0.0;
-#pragma unroll
-      for (int m = 0; m < kNB; ++m) tfrow[m] = 0.0;
-      double* tpp_row = tpp + r * kNB;
-      pivot_sweep_inplace<0, DF>(X, tfrow, tpp_row, myscl, wv, r, g);
-#pragma unroll
-      for (int T4 = 0; T4 < DF / 4; ++T4)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) Fl[(kNB * wv + r) * LDF + 64 * T4 + 16 * g + e] = X[16 * T4 + e];
-      if (g == 0) {
-        sclF[kNB * wv + r] = myscl;
-#pragma unroll
-        for (int m = 0; m < kNB; ++m) TfF[wv * kNB * kNB + r * kNB + m] = tfrow[m];
-      }
-      // forward substitution with the diagonal block (lower triangular, row r in tpp_row): lane r of every group alike
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      double crow[kNB];
-#pragma unroll
-      for (int m = 0; m < kNB; ++m) crow[m] = tpp_row[m];
-      double xsol = 0.0;
-      tri_forward16<0>(rhs, xsol, crow, r);
-      if (g == 0) wz[kNB * wv + r] = xsol;
-    }
-    __syncthreads();
-    if (owner && wv > pnl) {
-      double4_t unused;
-      apply_panel_to_strip<DF, LDF>(X, Fl + pnl * kNB * LDF, TfF + pnl * kNB * kNB, sclF + pnl * kNB, double4_t{0.0, 0.0, 0.0, 0.0},
-                                    unused, r, g);
-    }
-  }
-  __syncthreads();
-  CK_STAMP(6);
-  strip_update_body<DT, DD>(v, arg, K, b, Fl, TfF, sclF, wz, red);
-  CK_STAMP(7);
-#ifdef PNODE_TIMING_BUILD
-  if (tid == 0) {
-    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(v.S + size_t(b) * d * d) + 64;
-    for (int i = 0; i < 8; ++i) dbg[i] = ck_acc[i];
-  }
-#endif
 }
 
 bool dense_mfma_supported(const DenseView& v) {
@@ -858,18 +967,25 @@ static void launch_mfma(const DenseView& v, const StepArg* args, const IwpConst*
   }
   mark(3);
   constexpr int d = 16 * DD;
-  static_assert(DD <= 4, "the error norm is computed by strip block 0, which must cover the d rows of u");
-  // 2 d (d + 1) >= d (2d + 1) for the two lives of the big buffer, then TfF, sclF, tpp, wz, red: see the kernel
-  const size_t shm1 = (size_t(2) * d * (d + 1) + size_t(DD) * 256 + d + 256 + 2 * d + 8) * sizeof(double);
+  hipLaunchKernelGGL((dense_gain_mfma_kernel<DT, DD>), dim3(v.B), dim3(256), 0, s, v, args, K);
+  // workgroups per trajectory of the strip rotation: one where the batch fills the chip anyway (the reflector panels are staged
+  // once per workgroup), two below that (latency of a small batch); the arithmetic of a strip does not depend on the split
+  constexpr int NY2 = (DT % 8 == 0 && (DT / 2) * 16 >= d) ? 2 : 1;
+  const size_t shm1 = (size_t(d) * (2 * d + 1) + size_t(DD) * 256 + d + 2 * d + 8) * sizeof(double);
   int dev = 0;
   (void)hipGetDevice(&dev);
   static bool attr1[64] = {};  // the opt-in to > 64 KB of dynamic LDS is per function AND per device
   if (!attr1[dev & 63]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_correct_mfma_kernel<DT, DD>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_rotate_mfma_kernel<DT, DD, 1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, int(shm1));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_rotate_mfma_kernel<DT, DD, NY2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, int(shm1));
     attr1[dev & 63] = true;
   }
-  hipLaunchKernelGGL((dense_correct_mfma_kernel<DT, DD>), dim3(v.B), dim3(256), shm1, s, v, args, K);
+  if (v.B >= 512 || NY2 == 1)
+    hipLaunchKernelGGL((dense_rotate_mfma_kernel<DT, DD, 1>), dim3(v.B, 1), dim3(256), shm1, s, v, args, K);
+  else
+    hipLaunchKernelGGL((dense_rotate_mfma_kernel<DT, DD, NY2>), dim3(v.B, NY2), dim3(256), shm1, s, v, args, K);
   mark(4);
 }
 

@@ -80,15 +80,6 @@ __device__ __forceinline__ double sum_over_groups(double v) {
   return __hiloint2double(e[0], c[0]) + __hiloint2double(e[1], c[1]);
 }
 
-// acc += tfrow[M] * u(lane M of the row), M = 0 .. C-1: one DPP-operand FMA per term
-template <int M, int C>
-__device__ __forceinline__ void tf_accumulate(double& acc, double u, const double (&tfrow)[kNB]) {
-  if constexpr (M < C) {
-    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(u), "v"(tfrow[M]), "i"(M));
-    tf_accumulate<M + 1, C>(acc, u, tfrow);
-  }
-}
-
 // Lane predicates of the sweep as LITERAL lane masks (lane l holds row l & 15): a select costs two v_cndmask_b32 with the mask
 // in an SGPR pair (s_mov_b64 on the scalar unit) instead of v_cmp + wait states + v_cndmask on the vector unit. The sweep is
 // bound by the number of vector instructions a wavefront issues between the FMAs (scripts/dpp_probe.hip: 5.6 cycles per DPP FMA,
@@ -217,17 +208,20 @@ __device__ __forceinline__ void pivot_sweep(double (&X)[4 * DT], double (&tfrow)
 //   reflector C:  v_C = scl_C * xhat_C,  xhat_C = [0 .. 0, 1 / scl_C (pivot column), x_C (columns beyond)],  H_C = I - tau_C v_C^T v_C
 // The rows stay unscaled in the registers (the pivot entry 1 / scl_C = -beta tau is stored in place), so that the panel
 // applies to other strips as a plain product with no separate unit part.
-// tpp_row[C] <- C-factor entry [row r][column C of the panel];  tfrow[C]: compact-WY factor as in pivot_step.
+// tpp_row[C] <- C-factor entry [row r][column C of the panel] for r >= C (the reader masks the upper triangle);
+// tfrow[C]: compact-WY factor as in pivot_step.
 // ---------------------------------------------------------------------------------------------------------------------
+template <int C> constexpr unsigned long long kRowsFrom = rep4(0xFFFFu << C);  // r >= C
 template <int C, int DT>
 __device__ __forceinline__ void pivot_step_inplace(double (&X)[4 * DT], double (&tfrow)[kNB], double* __restrict__ tpp_row,
-                                                   double& myscl, int gp, int r_, int g_) {
-  int r = r_, g = g_;
-  asm volatile("" : "+v"(r), "+v"(g));
+                                                   double& myscl, int gp, int g_) {
+  int g = g_;
+  asm volatile("" : "+v"(g));
   const bool pivcol = g == gp;
   // the strip's entries in the pivot column, delivered to every lane of their row; cleared in the rows >= C
   const double t_r = sum_over_groups(pivcol ? X[C] : 0.0);
-  X[C] = (pivcol && r >= C) ? 0.0 : X[C];
+  const double xc_cleared = sel_mask_or_zero<~kRowsFrom<C>>(X[C]);
+  X[C] = pivcol ? xc_cleared : X[C];
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
   for (int e = 0; e < 4 * DT; e += 16)
@@ -236,42 +230,46 @@ __device__ __forceinline__ void pivot_step_inplace(double (&X)[4 * DT], double (
   const double dotv = sum_over_groups((a0 + a1) + (a2 + a3));  // x_r . x_C over the columns beyond the pivot
   const double xx = bcast16<C>(dotv);
   const double alpha = bcast16<C>(t_r);
-  double tauc = 0.0, scale = 0.0, beta = alpha;
-  {
-    const double nrm2 = fma(alpha, alpha, xx);
-    const double rs = fast_rsqrt(nrm2);
-    const double sgn = copysign(1.0, alpha);
-    const double t1 = fma(fabs(alpha), rs, 1.0);
-    const bool refl = xx != 0.0;
-    beta = refl ? -sgn * nrm2 * rs : alpha;
-    tauc = refl ? t1 : 0.0;
-    scale = refl ? sgn * rs * fast_rcp(t1) : 0.0;
-  }
+  // (a pivot row without an entry beyond the pivot is reflected like any other: v = e_C, tau = 2; see pivot_step)
+  const double nrm2 = fma(alpha, alpha, xx) + 1e-200;
+  const double rs = fast_rsqrt(nrm2);
+  const double beta = -copysign(nrm2 * rs, alpha);
+  const double tauc = fma(fabs(alpha), rs, 1.0);
+  const double scale = copysign(rs, alpha) * fast_rcp(tauc);
   const double gr = fma(scale, dotv, t_r);  // (row r) . v_C
   const double w = tauc * gr;
-  const double nws = (r > C) ? -(w * scale) : 0.0;
-  tpp_row[C] = (r > C) ? t_r - w : ((r == C) ? beta : 0.0);
-  {
-    const double u = (r < C) ? myscl * gr : 0.0;  // v_r . v_C for the finished reflectors r < C
-    double acc = 0.0;
-    tf_accumulate<0, C>(acc, u, tfrow);
-    tfrow[C] = (r < C) ? -tauc * acc : ((r == C) ? tauc : 0.0);
+  const double nws = sel_mask_or_zero<kRowsBelow<C>>(-(w * scale));
+  tpp_row[C] = sel_mask<kRowIs<C>>(beta, t_r - w);  // (rows r < C: not meaningful, the reader masks the upper triangle)
+  double tfc;
+  if constexpr (C > 0) {
+    const double u = myscl * gr;  // v_r . v_C for the finished reflectors r < C (only their lanes are read)
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    tf_block<0, C>(acc, u, tfrow);
+    const double ind = sel_mask_or_zero<kRowIs<C>>(1.0);
+    tfc = tauc * (ind - ((acc[0] + acc[1]) + (acc[2] + acc[3])));
+  } else {
+    tfc = sel_mask_or_zero<kRowIs<C>>(tauc);
   }
-  myscl = (r == C) ? scale : myscl;
+  tfrow[C] = tfc;
+  myscl = sel_mask<kRowIs<C>>(scale, myscl);
   asm volatile("" : "+v"(tfrow[C]), "+v"(myscl));
+  if constexpr (C + 1 < kNB) {
 #pragma unroll
-  for (int e = 0; e < 4 * DT; e += 16)
-    upd16<C>(X[e], X[e + 1], X[e + 2], X[e + 3], X[e + 4], X[e + 5], X[e + 6], X[e + 7], X[e + 8], X[e + 9], X[e + 10], X[e + 11],
-             X[e + 12], X[e + 13], X[e + 14], X[e + 15], nws);
-  X[C] = (pivcol && r == C) ? -(beta * tauc) : X[C];  // 1 / scl_C = alpha - beta = -beta tau  (0 without a reflection)
+    for (int e = 0; e < 4 * DT; e += 16)
+      upd16<C>(X[e], X[e + 1], X[e + 2], X[e + 3], X[e + 4], X[e + 5], X[e + 6], X[e + 7], X[e + 8], X[e + 9], X[e + 10], X[e + 11],
+               X[e + 12], X[e + 13], X[e + 14], X[e + 15], nws);
+  }
+  // 1 / scl_C = alpha - beta = -beta tau in place, on the pivot lane of the pivot column
+  const double piv = sel_mask<kRowIs<C>>(-(beta * tauc), X[C]);
+  X[C] = pivcol ? piv : X[C];
 }
 
 template <int C, int DT>
 __device__ __forceinline__ void pivot_sweep_inplace(double (&X)[4 * DT], double (&tfrow)[kNB], double* __restrict__ tpp_row,
-                                                    double& myscl, int gp, int r, int g) {
+                                                    double& myscl, int gp, int g) {
   if constexpr (C < kNB) {
-    pivot_step_inplace<C, DT>(X, tfrow, tpp_row, myscl, gp, r, g);
-    pivot_sweep_inplace<C + 1, DT>(X, tfrow, tpp_row, myscl, gp, r, g);
+    pivot_step_inplace<C, DT>(X, tfrow, tpp_row, myscl, gp, g);
+    pivot_sweep_inplace<C + 1, DT>(X, tfrow, tpp_row, myscl, gp, g);
   }
 }
 

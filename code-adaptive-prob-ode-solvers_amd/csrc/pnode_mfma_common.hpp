@@ -66,6 +66,18 @@ __device__ __forceinline__ size_t tiled_index(int row, int col) {  // element in
   return ((size_t(s) * (2 * DC) + 8 * T + (e >> 1)) * 64 + r + 16 * g) * 2 + (e & 1);
 }
 
+// The LQ's output for the columns < 2d ("T scratch", v.R; read by the measurement update only) is stored in strip order too, with
+// the columns of every 64-column super-tile PERMUTED so that the four columns one v_mfma_f64_16x16x4 contracts come from ONE
+// 16-column tile: register e = 4 a + q of lane group g holds column 64 T + 16 a + 4 q + g (a = tile, q = 0..3). That is the C/D
+// fragment of a 16 x 16 tile as the matrix core delivers it, so the LQ stores its tiles without a transpose, 1 KB per
+// instruction, and the measurement update can skip the 16-column tiles in which a reflector panel of F is structurally zero.
+// DCT = 2d / 16 column tiles.
+template <int DCT>
+__device__ __forceinline__ size_t tiledpi_index(int row, int col) {
+  const int s = row >> 4, r = row & 15, T = col >> 6, a = (col >> 4) & 3, q = (col >> 2) & 3, g = col & 3, e = 4 * a + q;
+  return ((size_t(s) * (2 * DCT) + 8 * T + (e >> 1)) * 64 + r + 16 * g) * 2 + (e & 1);
+}
+
 // 4 x 4 transpose of a C/D fragment among the four 16-lane rows of the wavefront: in, lane (r, g) holds columns g + 4 q of
 // row r (q = 0..3); out, columns 4 g + q -- four CONSECUTIVE columns per lane, so that a tile of T leaves the wavefront in
 // whole 128-byte rows instead of scattered 8-byte pieces. Two rounds of v_permlane32_swap / v_permlane16_swap (gfx950).

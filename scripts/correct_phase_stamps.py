@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""In-kernel cycle stamps of dense_correct_mfma_kernel (wavefront 0 of a workgroup) from the DIAGNOSTIC library
+"""In-kernel cycle stamps of dense_gain_mfma_kernel (every wavefront of a workgroup) from the DIAGNOSTIC library
 (make -C csrc timing).   python scripts/correct_phase_stamps.py [B]"""
 import ctypes as C, os, sys
 import numpy as np
@@ -26,14 +26,14 @@ lib.pnode_debug_read_scratch.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_i
 for it in range(3):
     bt.attempt_step(np.full(B, 0.005), one, err)
     bt.commit(one)
-names = ["stage J, T11", "F1 (MFMA)", "F -> LDS/global", "S = F F^T", "S -> LDS", "Cholesky", "Dinv, w, TRSM", "W -> LDS, strips"]
-tot = np.zeros(8)
+names = ["form F", "barrier (z)", "sweep", "barrier A", "publish + forward", "barrier B", "apply", "-"]
+tot = np.zeros((4, 8))
 pick = list(range(0, B, max(1, B // 16)))
 for b in pick:
-    out = (C.c_uint64 * 8)()
-    assert lib.pnode_debug_read_scratch(bt._h, b, 64, 8, out) == 0
-    tot += np.array(list(out), dtype=np.float64) / len(pick)
-print(f"B={B}: dense_correct_mfma_kernel, cycles of wavefront 0 by phase, mean of {len(pick)} workgroups")
-for n, x in zip(names, tot):
-    print(f"  {n:>18s} {x:10.0f}")
-print(f"  {'total':>18s} {tot.sum():10.0f}")
+    out = (C.c_uint64 * 32)()
+    assert lib.pnode_debug_read_scratch(bt._h, b, 64, 32, out) == 0
+    tot += np.array(list(out), dtype=np.float64).reshape(4, 8) / len(pick)
+print(f"B={B}: dense_gain_mfma_kernel, cycles per wavefront (rows) by phase (columns), mean of {len(pick)} workgroups")
+print("wave " + " ".join(f"{n:>18s}" for n in names) + "      total")
+for w in range(4):
+    print(f"{w:4d} " + " ".join(f"{x:18.0f}" for x in tot[w]) + f" {tot[w].sum():10.0f}")
