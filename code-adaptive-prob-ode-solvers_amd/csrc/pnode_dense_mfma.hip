@@ -596,12 +596,12 @@ __global__ __launch_bounds__(256) void dense_begin_mfma_kernel(DenseView v, cons
 //   F = H L^- (d x 2d: L^- is lower triangular),  F = [C 0] Q^T by a blocked row-Householder LQ (S = C C^T is never formed),
 //   L^- Q = [Y1 | Y2 | columns >= 2d]:  gain K = Y1 C^-1, mean m = m^- - Y1 (C^-1 z), and [Y2 | columns >= 2d] is a factor of the
 //   updated covariance with D - d columns -- the observation is noise-free, the d directions of Y1 are known exactly afterwards.
-// Two kernels (r03; one until then, 0.31 ms at B = 1024: its serial first half left the matrix core to a second workgroup only):
-//   dense_gain_mfma_kernel   -- F, its LQ, C^-1 z. A chain of d pivots: latency. Almost no LDS (one panel), three workgroups per CU.
-//   dense_rotate_mfma_kernel -- every 16-row strip of L^- rotated by the reflector panels: matrix-core streaming, NY workgroups
-//                               per trajectory; the 16-column tiles in which a panel is structurally zero are skipped.
-// Hand-over through the F scratch (v.Ft, per trajectory): reflector rows [d][2d] in strip order, Tf [d/16][16][16], scl [d],
-// C^-1 z [2d] (zeros beyond d).
+// ONE kernel per trajectory, two workgroups per CU: the first half (F, its LQ, C^-1 z) is a chain of d pivots, latency; the second
+// (every 16-row strip of L^- rotated by the reflector panels, which stay in LDS) is matrix-core streaming and fills the SIMDs
+// while the other workgroup of the CU is in its first half. (r03 also measured the two halves as two kernels -- the first with
+// 22 KB of LDS, the second with one or two workgroups per trajectory: 0.142 + 0.142 ms at B = 1024 against 0.31 for the r02
+// kernel; the chain kernel leaves the CUs idle, three of its workgroups do not fit the register file: git show 5a0f4f1^.)
+// The 16-column tiles in which a panel is structurally zero are skipped (176 instead of 272 MFMAs per strip).
 // ---------------------------------------------------------------------------------------------------------------------
 
 // Panel p of the LQ of F = [p1 T21 - p0 J T11 | p1 T22] (T22 lower triangular) is non-zero in the 16-column tiles p .. DD - 1 of
@@ -666,57 +666,36 @@ __device__ __forceinline__ void apply_all_panels(double (&X)[4 * DF], const doub
   }
 }
 
-// Offsets (in doubles) into the per-trajectory F scratch
-template <int DD> struct GainScratch {
-  static constexpr int d = 16 * DD, W2 = 2 * d;
-  static constexpr int V = 0, Tf = d * W2, scl = Tf + DD * kNB * kNB, wz = scl + d, size = wz + W2;
-};
-
 template <int DT, int DD>
-__global__ __launch_bounds__(256, 2) void dense_gain_mfma_kernel(DenseView v, const StepArg* __restrict__ args,
-                                                                 const IwpConst* __restrict__ Kc) {
-  constexpr int D = 16 * DT, d = 16 * DD, W2 = 2 * d, LDF = W2 + 1, DF = W2 / 16, DCT = DF;
+__global__ __launch_bounds__(256, 2) void dense_correct_mfma_kernel(DenseView v, const StepArg* __restrict__ args,
+                                                                    const IwpConst* __restrict__ Kc) {
+  constexpr int D = 16 * DT, d = 16 * DD, W2 = 2 * d, LDF = W2 + 1, DF = W2 / 16, DCT = DF, DC = mfma_col_tiles(DT, DD);
   static_assert(DD <= 4, "one wavefront per 16-row strip of F; the pivot columns of a strip lie in the first super-tile");
-  static_assert(GainScratch<DD>::size <= d * D, "the F scratch holds the hand-over");
-  __shared__ double Vs[kNB * LDF];     // the panel being applied (unscaled reflector rows, pivot entries 1 / scl)
-  __shared__ double TfS[kNB * kNB];
-  __shared__ double sclS[kNB];
-  __shared__ double tpp[kNB * kNB];    // diagonal block of C of the sweeping wavefront
-  __shared__ double wz[W2];            // z, then C^-1 z block by block; zeros beyond d
+  static_assert(DT % 4 == 0, "whole strips per wavefront");
+  extern __shared__ double gbuf[];
+  double* Vf = gbuf;                      // [d][LDF]  reflector rows (unscaled, pivot entries 1 / scl): plain column order during the
+                                          //           LQ of F, the tile-aligned order of the strips (tiledpi_index) afterwards
+  double* TfF = Vf + d * LDF;             // [DD][16][16]
+  double* sclF = TfF + DD * kNB * kNB;    // [d]
+  double* tpp = sclF + d;                 // [16][16]  diagonal block of C of the sweeping wavefront
+  double* wz = tpp + kNB * kNB;           // [2d] z, then C^-1 z block by block; zeros beyond d
+  double* tv = wz + W2;                   // [2d] C^-1 z in the column order of the strips
+  double* red = tv + W2;                  // [4]
   const int b = blockIdx.x;
   const StepArg arg = args[b];
   if (!arg.active) return;
   const IwpConst& K = *Kc;
-  const int tid = threadIdx.x, lane = tid & 63;
-  // Strip w of F is owned by wavefront (w + blockIdx) mod 4: the workgroups that share a CU run in lockstep, and a sweep is a pure
-  // vector-ALU stream; with the same wavefront number sweeping in all of them, the sweeps would queue on ONE SIMD.
-  const int wv = ((tid >> 6) + 4 - (blockIdx.x & 3)) & 3;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   double p[kMaxN], pinv[kMaxN];
   precond_rt(v.n, arg.dt, K, p, pinv);
   const double p0 = p[0], p1 = p[1];
   const double* __restrict__ T = v.R + size_t(b) * D * D;  // tile-aligned strip order, columns < 2d (tiledpi_index)
   const double* __restrict__ Jg = v.J + size_t(b) * d * d;
-  double* __restrict__ hand = v.Ft + size_t(b) * d * D;
   for (int j = tid; j < W2; j += 256) wz[j] = j < d ? v.z[size_t(b) * d + j] : 0.0;
   const bool owner = wv < DD;
-#ifdef PNODE_TIMING_BUILD
-  // diagnostic build only: cycle sums by phase per wavefront, written behind the LQ's stamps in the S scratch
-  unsigned long long ck_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long ck_prev = __builtin_amdgcn_s_memtime();
-#define CK_STAMP(slot)                                             \
-  do {                                                             \
-    const unsigned long long now_ = __builtin_amdgcn_s_memtime();  \
-    ck_acc[slot] += now_ - ck_prev;                                \
-    ck_prev = now_;                                                \
-  } while (0)
-#else
-#define CK_STAMP(slot) \
-  do {                 \
-  } while (0)
-#endif
   // ---- my strip of F in registers, plain strip order: X[16 T + e] = F[16 wv + r][64 T + 16 g + e]
-  //      F = p1 T[d + ., 0 : 2d] - p0 [J T11 | 0]   (the rows d .. 2d-1 of T end at their diagonal entry: zeros are stored there)
+  //      F = p1 T[d + ., 0 : 2d] - p0 [J T11 | 0]
   double X[4 * DF];
   if (owner) {
     // (addresses as ONE lane-dependent base + compile-time offsets: through tiledpi_index the compiler keeps a 64-bit address
@@ -752,19 +731,14 @@ __global__ __launch_bounds__(256, 2) void dense_gain_mfma_kernel(DenseView v, co
       for (int s4 = 0; s4 < d / 4; ++s4) acc = MFMA64(aop[s4], jrow[s4], acc);
 #pragma unroll
       for (int i = 0; i < 4; ++i) X[4 * j + i] += acc[i];
-      __builtin_amdgcn_sched_barrier(0);  // (one tile's operands at a time: hoisted together they cost 128 registers)
+      __builtin_amdgcn_sched_barrier(0);  // (one tile's operands at a time)
     }
   }
-  CK_STAMP(0);
   __syncthreads();  // wz
-  CK_STAMP(1);
-  // ---- blocked row-Householder LQ of F: wavefront w sweeps strip w in registers (pnode_lq_sweep.hpp), the panel goes through
-  //      ONE LDS buffer (two barriers per panel) and to the hand-over scratch
+  // ---- blocked row-Householder LQ of F: wavefront w sweeps strip w in registers (pnode_lq_sweep.hpp); its panel stays in LDS
 #pragma unroll 1
   for (int pnl = 0; pnl < DD; ++pnl) {
-    double tfrow[kNB], myscl = 0.0, rhs = 0.0;
-    const bool mine = owner && wv == pnl;
-    if (mine) {
+    if (owner && wv == pnl) {
       // my columns before the panel are final entries of C (row block wv): their share of the forward substitution
       //   rhs = z - C[rows, 0 : 16 wv] (C^-1 z)[0 : 16 wv]
       // is taken here, then they leave the strip (the reflectors of this panel act on the columns >= 16 wv only)
@@ -776,32 +750,19 @@ __global__ __launch_bounds__(256, 2) void dense_gain_mfma_kernel(DenseView v, co
           X[e] = 0.0;
         }
       }
-      rhs = wz[kNB * wv + r] - sum_over_groups(part);
+      double rhs = wz[kNB * wv + r] - sum_over_groups(part);
+      double tfrow[kNB], myscl = 0.0;
 #pragma unroll
       for (int m = 0; m < kNB; ++m) tfrow[m] = 0.0;
       pivot_sweep_inplace<0, DF>(X, tfrow, tpp + r * kNB, myscl, wv, g);
-      CK_STAMP(2);
-    }
-    __syncthreads();  // (A) every wavefront is done with the previous panel in Vs
-    CK_STAMP(3);
-    if (mine) {
-      double* __restrict__ hv = hand + GainScratch<DD>::V;
 #pragma unroll
       for (int T4 = 0; T4 < DF / 4; ++T4)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          Vs[r * LDF + 64 * T4 + 16 * g + e] = X[16 * T4 + e];
-          if ((e & 1) == 0)  // hand-over: the strip in register order (pair pp of lane l at double2 index (wv 2 DF + pp) 64 + l)
-            reinterpret_cast<double2*>(hv)[(size_t(wv) * (2 * DF) + 8 * T4 + e / 2) * 64 + lane] = double2{X[16 * T4 + e], X[16 * T4 + e + 1]};
-        }
+        for (int e = 0; e < 16; ++e) Vf[(kNB * wv + r) * LDF + 64 * T4 + 16 * g + e] = X[16 * T4 + e];
       if (g == 0) {
-        sclS[r] = myscl;
-        hand[GainScratch<DD>::scl + kNB * wv + r] = myscl;
+        sclF[kNB * wv + r] = myscl;
 #pragma unroll
-        for (int m = 0; m < kNB; ++m) {
-          TfS[r * kNB + m] = tfrow[m];
-          hand[GainScratch<DD>::Tf + wv * kNB * kNB + r * kNB + m] = tfrow[m];
-        }
+        for (int m = 0; m < kNB; ++m) TfF[wv * kNB * kNB + r * kNB + m] = tfrow[m];
       }
       // forward substitution with the diagonal block (lower triangular, row r in tpp): lane r of every group alike
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -810,96 +771,58 @@ __global__ __launch_bounds__(256, 2) void dense_gain_mfma_kernel(DenseView v, co
       for (int m = 0; m < kNB; ++m) crow[m] = (m <= r) ? tpp[r * kNB + m] : 0.0;  // (the sweep leaves the upper triangle unwritten)
       double xsol = 0.0;
       tri_forward16<0>(rhs, xsol, crow, r);
-      if (g == 0) {
-        wz[kNB * wv + r] = xsol;
-        hand[GainScratch<DD>::wz + kNB * wv + r] = xsol;
-      }
-      CK_STAMP(4);
+      if (g == 0) wz[kNB * wv + r] = xsol;
     }
-    __syncthreads();  // (B) the panel is in Vs
-    CK_STAMP(5);
+    __syncthreads();
     if (owner && wv > pnl) {
       double4_t unused;
-      apply_panel_to_strip<DF, LDF>(X, Vs, TfS, sclS, double4_t{0.0, 0.0, 0.0, 0.0}, unused, r, g);
-      CK_STAMP(6);
-    }
-  }
-  for (int j = d + tid; j < W2; j += 256) hand[GainScratch<DD>::wz + j] = 0.0;
-#ifdef PNODE_TIMING_BUILD
-  if (lane == 0) {
-    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(v.S + size_t(b) * d * d) + 64 + 8 * wv;
-    for (int i = 0; i < 8; ++i) dbg[i] = ck_acc[i];
-  }
-#endif
-}
-
-// Rotation of the strips of L^- = diag(p) T (first 2d columns) by the reflector panels of F: X Q = [Y1 | Y2]. Y1 = L^- W^T feeds
-// the mean, Y2 = L^- Q2 becomes the dense part of the new rank-(D - d) state factor (its columns 0 .. d-1, in the order the
-// registers hold them: the column order of a factor is immaterial); the columns >= 2d of L^- were written by the LQ kernel as
-// the columns >= d of Ls, already scaled. Workgroup y of NY takes the strips [DT / NY * y, DT / NY * (y + 1)); workgroup 0, which
-// holds the rows of the zeroth derivative, forms the normalised error norm.
-template <int DT, int DD, int NY>
-__global__ __launch_bounds__(256, 2) void dense_rotate_mfma_kernel(DenseView v, const StepArg* __restrict__ args,
-                                                                   const IwpConst* __restrict__ Kc) {
-  constexpr int D = 16 * DT, d = 16 * DD, W2 = 2 * d, LDF = W2 + 1, DF = W2 / 16, DCT = DF, DC = mfma_col_tiles(DT, DD);
-  static_assert(DT % (4 * NY) == 0 && (DT / NY) * 16 >= d, "whole strips per wavefront; workgroup 0 covers the rows of u");
-  extern __shared__ double gbuf[];
-  double* Vf = gbuf;                      // [d][LDF]  reflector rows, columns in the tile-aligned order of the strips
-  double* TfF = Vf + d * LDF;             // [DD][16][16]
-  double* sclF = TfF + DD * kNB * kNB;    // [d]
-  double* tv = sclF + d;                  // [2d] C^-1 z in the same column order, zeros for the columns >= d
-  double* red = tv + W2;                  // [4]
-  const int b = blockIdx.x, y = blockIdx.y;
-  const StepArg arg = args[b];
-  if (!arg.active) return;
-  const IwpConst& K = *Kc;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int r = lane & 15, g = lane >> 4;
-  const double* __restrict__ hand = v.Ft + size_t(b) * d * D;
-  // ---- stage the hand-over: the reflector strips are in plain register order (register e of group g: column 64 T + 16 g + e);
-  //      in the LDS image the slot [64 T + 16 g' + e'] holds column 64 T + 16 (e' >> 2) + 4 (e' & 3) + g'
-  {
-    const double2* __restrict__ hv = reinterpret_cast<const double2*>(hand + GainScratch<DD>::V);
-    for (int idx = tid; idx < d * W2 / 2; idx += 256) {
-      const int l = idx & 63, pp = (idx >> 6) % (2 * DF), st = idx / (64 * 2 * DF);
-      const double2 t2 = hv[idx];
-      const int rr = l & 15, gs = l >> 4, T4 = pp >> 3, es = 2 * (pp & 7);  // plain order: columns 64 T + 16 gs + es, + 1
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int c = 16 * gs + es + h;  // column inside the super-tile
-        const int a = c >> 4, q = (c >> 2) & 3, gp = c & 3;
-        Vf[(kNB * st + rr) * LDF + 64 * T4 + 16 * gp + 4 * a + q] = h ? t2.y : t2.x;
-      }
-    }
-    for (int idx = tid; idx < DD * kNB * kNB; idx += 256) TfF[idx] = hand[GainScratch<DD>::Tf + idx];
-    for (int idx = tid; idx < d; idx += 256) sclF[idx] = hand[GainScratch<DD>::scl + idx];
-    for (int idx = tid; idx < W2; idx += 256) {  // slot idx = 64 T + 16 g' + e'
-      const int T4 = idx >> 6, gp = (idx >> 4) & 3, ep = idx & 15;
-      const int col = 64 * T4 + 16 * (ep >> 2) + 4 * (ep & 3) + gp;
-      tv[idx] = col < d ? hand[GainScratch<DD>::wz + col] : 0.0;
+      apply_panel_to_strip<DF, LDF>(X, Vf + pnl * kNB * LDF, TfF + pnl * kNB * kNB, sclF + pnl * kNB, double4_t{0.0, 0.0, 0.0, 0.0},
+                                    unused, r, g);
     }
   }
   __syncthreads();
-  const double* __restrict__ T = v.R + size_t(b) * D * D;
+  // ---- the panels from the plain column order to the order of the strips, in place: slot 16 g + e of a super-tile (plain:
+  //      column 16 g + e) moves to slot 16 (e & 3) + 4 g + (e >> 2) (there, register e' = 4 a + q of group g' is column
+  //      16 a + 4 q + g'); every thread takes half a super-tile of one row
+  {
+    const int prow = tid >> 2, pT = (tid >> 1) & 1, half = tid & 1;
+    const bool act = prow < d && pT < DF / 4;
+    double tmp[32];
+    double* rowp = Vf + prow * LDF + 64 * pT;
+    if (act) {
+#pragma unroll
+      for (int i = 0; i < 32; ++i) tmp[i] = rowp[32 * half + i];
+    }
+    __syncthreads();
+    if (act) {
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        const int k = 32 * half + i, gs = k >> 4, es = k & 15;
+        rowp[16 * (es & 3) + 4 * gs + (es >> 2)] = tmp[i];
+      }
+    }
+    for (int idx = tid; idx < W2; idx += 256) {  // slot idx = 64 T + 16 g' + e'
+      const int T4 = idx >> 6, gp = (idx >> 4) & 3, ep = idx & 15;
+      const int col = 64 * T4 + 16 * (ep >> 2) + 4 * (ep & 3) + gp;
+      tv[idx] = col < d ? wz[col] : 0.0;
+    }
+  }
+  __syncthreads();
+  // ---- every 16-row strip of L^- = diag(p) T (first 2d columns) rotated by the panels: X Q = [Y1 | Y2]. Y1 = L^- W^T feeds the
+  //      mean, Y2 = L^- Q2 becomes the dense part of the new rank-(D - d) state factor (its columns 0 .. d-1, in the order the
+  //      registers hold them: the column order of a factor is immaterial); the columns >= 2d of L^- were written by the LQ kernel
+  //      as the columns >= d of Ls, already scaled.
   const size_t sB = size_t(v.B);
   double* mdst = v.mean + (size_t(arg.dst) * sB + b) * D;
   double* __restrict__ Ln = v.U + (size_t(arg.dst) * sB + b) * D * D;
-  constexpr int SPW = DT / NY / 4;  // strips per wavefront
 #pragma unroll 1
-  for (int it = 0; it < SPW; ++it) {
-    const int st = (DT / NY) * y + wv + 4 * it;
+  for (int st = wv; st < DT; st += 4) {
     const int row = 16 * st + r;
     const int iblk = (16 * st) / d;
-    double pr;
-    {
-      double p[kMaxN], pinv[kMaxN];
-      precond_rt(v.n, arg.dt, K, p, pinv);
-      pr = p[0];
+    double pr = p[0];
 #pragma unroll
-      for (int i = 1; i < kMaxN; ++i) pr = (i == iblk) ? p[i] : pr;
-    }
+    for (int i = 1; i < kMaxN; ++i) pr = (i == iblk) ? p[i] : pr;
     // the strip of T in the order it was stored: 1 KB per load instruction
-    double X[4 * DF];
     const double2* __restrict__ trow = reinterpret_cast<const double2*>(T) + size_t(st) * (2 * DCT) * 64 + lane;
 #pragma unroll
     for (int pp = 0; pp < 2 * DF; ++pp) {
@@ -928,8 +851,8 @@ __global__ __launch_bounds__(256, 2) void dense_rotate_mfma_kernel(DenseView v, 
       for (int e = 8; e < 16; ++e) Ln[tiled_index<DC>(row, 16 * (g & 1) + (e - 8) + 8 * (g >> 1))] = X[e];
     }
   }
-  if (y == 0) {
-    // error norm over u = m[0] (rows 0 .. d-1 were updated above by this workgroup)
+  {
+    // error norm over u = m[0] (rows 0 .. d-1 were updated above)
     __syncthreads();
     const double atol = v.atol[b], rtol = v.rtol[b];
     double part = 0.0;
@@ -967,25 +890,16 @@ static void launch_mfma(const DenseView& v, const StepArg* args, const IwpConst*
   }
   mark(3);
   constexpr int d = 16 * DD;
-  hipLaunchKernelGGL((dense_gain_mfma_kernel<DT, DD>), dim3(v.B), dim3(256), 0, s, v, args, K);
-  // workgroups per trajectory of the strip rotation: one where the batch fills the chip anyway (the reflector panels are staged
-  // once per workgroup), two below that (latency of a small batch); the arithmetic of a strip does not depend on the split
-  constexpr int NY2 = (DT % 8 == 0 && (DT / 2) * 16 >= d) ? 2 : 1;
-  const size_t shm1 = (size_t(d) * (2 * d + 1) + size_t(DD) * 256 + d + 2 * d + 8) * sizeof(double);
+  const size_t shm1 = (size_t(d) * (2 * d + 1) + size_t(DD) * 256 + d + 256 + 4 * d + 8) * sizeof(double);  // Vf, TfF, sclF, tpp, wz, tv, red
   int dev = 0;
   (void)hipGetDevice(&dev);
   static bool attr1[64] = {};  // the opt-in to > 64 KB of dynamic LDS is per function AND per device
   if (!attr1[dev & 63]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_rotate_mfma_kernel<DT, DD, 1>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, int(shm1));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_rotate_mfma_kernel<DT, DD, NY2>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_correct_mfma_kernel<DT, DD>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, int(shm1));
     attr1[dev & 63] = true;
   }
-  if (v.B >= 512 || NY2 == 1)
-    hipLaunchKernelGGL((dense_rotate_mfma_kernel<DT, DD, 1>), dim3(v.B, 1), dim3(256), shm1, s, v, args, K);
-  else
-    hipLaunchKernelGGL((dense_rotate_mfma_kernel<DT, DD, NY2>), dim3(v.B, NY2), dim3(256), shm1, s, v, args, K);
+  hipLaunchKernelGGL((dense_correct_mfma_kernel<DT, DD>), dim3(v.B), dim3(256), shm1, s, v, args, K);
   mark(4);
 }
 
