@@ -7,7 +7,7 @@ import glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ses = os.path.join(ROOT, "gpurun_out", sys.argv[1])
-tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r03"
 prof = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 P = os.path.join(ROOT, "profiles")
 shutil.copy(os.path.join(prof, "summary.json"), os.path.join(P, f"{tag}_pmc_summary.json"))
@@ -39,7 +39,6 @@ if os.path.exists(dl):
     new = [l.rstrip("\n") for l in open(dl) if l.startswith("{")]
     names = {json.loads(l)["config"] + json.loads(l)["controller"] for l in new}
     path = os.path.join(P, f"{tag}_configs.jsonl")
-    cur = [l for l in open(path).read().rstrip("\n").split("\n")
-           if not ("config" in json.loads(l) and json.loads(l)["config"] + json.loads(l).get("controller", "") in names)]
+    cur = [l for l in (open(path).read().rstrip("\n").split("\n") if os.path.exists(path) else []) if l.strip() and not ("config" in json.loads(l) and json.loads(l)["config"] + json.loads(l).get("controller", "") in names)]
     open(path, "w").write("\n".join(cur + new) + "\n")
 print("profiles refreshed:", [(b, round(v), round(ms, 3)) for b, v, ms, _ in rows])
