@@ -113,49 +113,9 @@ __global__ void dense_ctl_kernel(TrajCtl* __restrict__ ctl, StepArg* __restrict_
   if (b >= B) return;
   TrajCtl c = ctl[b];
   StepArg a = args[b];
-  if (c.status != 0) {  // < 0: not taking part; 1, 2: done
-    if (a.active) {
-      a.active = 0;
-      args[b] = a;
-    }
-    return;
-  }
-  if (!first && a.active) {
-    const double e = err[b], dt = a.dt;
-    c.attempts += 1;
-    bool accept;
-    if (e != e) {
-      c.status = 2;  // NaN error estimate: stop (the reference accepts the NaN state and fails later)
-      accept = true;
-    } else {
-      const double le = log(e);
-      const double raw = cp.safety * exp(cp.n2 * c.log_prev - (cp.n1 + cp.n2) * le);
-      const double factor = fmax(cp.factor_min, fmin(raw, cp.factor_max));
-      if (e <= 1.0) c.log_prev = le;
-      c.dt = factor * dt;
-      accept = !(e > 1.0);
-    }
-    if (accept) {
-      c.s_if = c.s_sf;
-      c.t_if = c.t_sf;
-      c.s_sf = c.s_pr;
-      c.t_sf += dt;
-      c.steps += 1;
-      int fr = 0;
-      while (fr == c.s_if || fr == c.s_sf) ++fr;
-      c.s_pr = fr;
-    }
-    if (c.status == 0 && !(isfinite(c.dt) && isfinite(c.t_sf) && c.dt > 0.0)) c.status = 2;
-  }
-  if (c.status == 0 && !(c.t_sf + cp.numerical_zero < c.t_stop)) c.status = 1;
-  double dt = c.dt;
-  if (cp.clip) dt = fmin(dt, c.t_stop - c.t_sf);
-  a.active = c.status == 0 ? 1 : 0;
-  a.dt = a.active ? dt : 1.0;
-  a.t = c.t_sf;
-  a.src = c.s_sf;
-  a.dst = c.s_pr;
-  a.pad = 0;
+  const bool was_active = a.active != 0;
+  if (c.status != 0 && !was_active) return;
+  controller_decision(c, a, first ? 0.0 : err[b], cp, first != 0);
   args[b] = a;
   ctl[b] = c;
 }
@@ -509,16 +469,17 @@ static int check_fault(pnode_batch* h) {
   return fail(PNODE_EDEVICE, msg);
 }
 
-static void enqueue_step(pnode_batch* h, const StepArg* dargs, double* errnorm = nullptr, const PhaseEvents* events = nullptr) {
+static void enqueue_step(pnode_batch* h, const StepArg* dargs, double* errnorm = nullptr, const PhaseEvents* events = nullptr,
+                         const FusedControl* fc = nullptr) {
   h->stepped = true;
   if (h->dense) {
     const PhaseEvents* ev = h->phase_timing ? (events ? events : &h->phase) : nullptr;
     if (errnorm) {  // error norms to device memory (device-resident controller) instead of the pinned host buffer
       DenseView v = h->dn;
       v.errnorm = errnorm;
-      dense_launch_step(v, dargs, h->dK, h->stream, ev);
+      dense_launch_step(v, dargs, h->dK, h->stream, ev, fc);
     } else {
-      dense_launch_step(h->dn, dargs, h->dK, h->stream, ev);
+      dense_launch_step(h->dn, dargs, h->dK, h->stream, ev, fc);
     }
   } else if (errnorm) {
     IsoView v = h->iso;
@@ -544,9 +505,17 @@ static int advance_rounds_device(pnode_batch* h, TrajCtl* hCtl, const ControlPar
       for (auto& e : pe.ev) HIP_TRY(hipEventCreate(&e));
       h->phase_pool.push_back(pe);
     }
+  // MFMA path of the dense EKF1: the measurement-update kernel carries the controller's decision (three launches per attempt:
+  // begin, LQ, measurement update); every other path: controller kernel between the attempts
+  const bool fused = h->dense && dense_fused_control_supported(h->dn);
   for (int r = 0; r < rounds; ++r) {
-    enqueue_step(h, h->dArgs, h->dErr, per_round ? &h->phase_pool[size_t(r)] : nullptr);
-    hipLaunchKernelGGL(dense_ctl_kernel, dim3(blocks), dim3(256), 0, h->stream, h->dCtl, h->dArgs, h->dErr, cp, int(B), 0);
+    if (fused) {
+      const FusedControl fc{h->dCtl, h->dArgs, cp};
+      enqueue_step(h, h->dArgs, h->dErr, per_round ? &h->phase_pool[size_t(r)] : nullptr, &fc);
+    } else {
+      enqueue_step(h, h->dArgs, h->dErr, per_round ? &h->phase_pool[size_t(r)] : nullptr);
+      hipLaunchKernelGGL(dense_ctl_kernel, dim3(blocks), dim3(256), 0, h->stream, h->dCtl, h->dArgs, h->dErr, cp, int(B), 0);
+    }
   }
   if (h->step_timing) HIP_TRY(hipEventRecord(h->ev1, h->stream));
   HIP_TRY(hipGetLastError());

@@ -61,6 +61,54 @@ struct ControlParams {
   int32_t clip, max_iters;
 };
 
+// One controller decision of a trajectory between two attempts of the multi-kernel dense paths (dense_ctl_kernel, and the tail of
+// the fused measurement-update kernel): takes the error norm of the attempt just made (unless `first`), accepts / rejects,
+// applies the PI law, rotates the state slots and forms the arguments of the next attempt -- same arithmetic and order as the host
+// loop of pnode_solve_adaptive_save_at (control_proportional_integral + adaptive,
+// /root/reference/src/odecheckpts/ivpsolvers.py:52-53).
+__device__ __forceinline__ void controller_decision(TrajCtl& c, StepArg& a, double e, const ControlParams& cp, bool first) {
+  if (c.status != 0) {  // < 0: not taking part; 1, 2: done
+    a.active = 0;
+    return;
+  }
+  if (!first && a.active) {
+    const double dt = a.dt;
+    c.attempts += 1;
+    bool accept;
+    if (e != e) {
+      c.status = 2;  // NaN error estimate: stop (the reference accepts the NaN state and fails later)
+      accept = true;
+    } else {
+      const double le = log(e);
+      const double raw = cp.safety * exp(cp.n2 * c.log_prev - (cp.n1 + cp.n2) * le);
+      const double factor = fmax(cp.factor_min, fmin(raw, cp.factor_max));
+      if (e <= 1.0) c.log_prev = le;
+      c.dt = factor * dt;
+      accept = !(e > 1.0);
+    }
+    if (accept) {
+      c.s_if = c.s_sf;
+      c.t_if = c.t_sf;
+      c.s_sf = c.s_pr;
+      c.t_sf += dt;
+      c.steps += 1;
+      int fr = 0;
+      while (fr == c.s_if || fr == c.s_sf) ++fr;
+      c.s_pr = fr;
+    }
+    if (c.status == 0 && !(isfinite(c.dt) && isfinite(c.t_sf) && c.dt > 0.0)) c.status = 2;
+  }
+  if (c.status == 0 && !(c.t_sf + cp.numerical_zero < c.t_stop)) c.status = 1;
+  double dt = c.dt;
+  if (cp.clip) dt = fmin(dt, c.t_stop - c.t_sf);
+  a.active = c.status == 0 ? 1 : 0;
+  a.dt = a.active ? dt : 1.0;
+  a.t = c.t_sf;
+  a.src = c.s_sf;
+  a.dst = c.s_pr;
+  a.pad = 0;
+}
+
 // IWP(nu) constants in preconditioned coordinates, computed on the host in fp64.
 //   a[i][k]   = binom(nu-i, nu-k)           (upper triangular)
 //   qsT[c][i] = chol(Qbar)^T                (upper triangular),  Qbar[i][j] = 1/(2nu+1-i-j)

@@ -409,8 +409,15 @@ bool dense_state_factor_tiled(const DenseView& v) {
   return dense_mfma_supported(v) && !v.force_generic;
 }
 
+// The register-resident MFMA kernels of the EKF1: their measurement-update kernel can carry the controller's decision.
+bool dense_fused_control_supported(const DenseView& v) {
+  if (dense_small_supported(v) && !v.force_generic) return false;
+  if (dense_use_large(v)) return false;
+  return dense_mfma_supported(v) && !v.force_generic && v.ts1 && !v.fixedpoint;
+}
+
 void dense_launch_step(const DenseView& v, const StepArg* args, const IwpConst* K, hipStream_t s,
-                       const PhaseEvents* ev) {
+                       const PhaseEvents* ev, const FusedControl* fc) {
   auto mark = [&](int i) {
     if (ev) (void)hipEventRecord(ev->ev[i], s);
   };
@@ -426,13 +433,13 @@ void dense_launch_step(const DenseView& v, const StepArg* args, const IwpConst* 
     return;
   }
   const size_t shm_begin = (size_t(v.k) * v.d + v.d + 4 + size_t(v.n) * v.n) * sizeof(double);
-  if (fast && v.ts1)
+  if (fast && v.ts1) {
     dense_launch_mfma_begin(v, args, K, s);
-  else
+  } else
     hipLaunchKernelGGL(dense_begin_kernel, dim3(v.B), dim3(kThreads), shm_begin, s, v, args, K);
   mark(1);
   if (fast) {
-    dense_launch_mfma_tail(v, args, K, s, ev);
+    dense_launch_mfma_tail(v, args, K, s, ev, (fc && v.ts1) ? fc : nullptr);
     return;
   }
   const int rows_per = v.D < 64 ? v.D : 64;

@@ -499,18 +499,12 @@ __device__ __forceinline__ void lds_forward_vec_wave(const double* Sm, double* x
   __syncthreads();
 }
 
+// First phase of an attempt: mean extrapolation, vector field and Jacobian at the extrapolated mean, unit-noise innovation S1 and its Cholesky
+// factor, local calibration sigma_hat, error estimate. Sm: [d][d + 1], ybuf, zbuf: [d], red: [4] doubles of LDS.
 template <int DD>
-__global__ __launch_bounds__(256) void dense_begin_mfma_kernel(DenseView v, const StepArg* __restrict__ args,
-                                                               const IwpConst* __restrict__ Kc) {
+__device__ __forceinline__ void begin_body(const DenseView& v, const StepArg& arg, const IwpConst& K, int b, double* Sm, double* ybuf,
+                                           double* zbuf, double* red) {
   constexpr int d = 16 * DD, LD = d + 1;
-  __shared__ double Sm[d * LD];
-  __shared__ double ybuf[d];
-  __shared__ double zbuf[d];
-  __shared__ double red[4];
-  const int b = blockIdx.x;
-  const StepArg arg = args[b];
-  if (!arg.active) return;
-  const IwpConst& K = *Kc;
   const int n = v.n;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
@@ -590,6 +584,20 @@ __global__ __launch_bounds__(256) void dense_begin_mfma_kernel(DenseView v, cons
   if (tid == 0) v.sig_new[b] = v.dynamic ? sigma_hat : v.sigma[size_t(arg.src) * sB + b];
 }
 
+template <int DD>
+__global__ __launch_bounds__(256) void dense_begin_mfma_kernel(DenseView v, const StepArg* __restrict__ args,
+                                                               const IwpConst* __restrict__ Kc) {
+  constexpr int d = 16 * DD, LD = d + 1;
+  __shared__ double Sm[d * LD];
+  __shared__ double ybuf[d];
+  __shared__ double zbuf[d];
+  __shared__ double red[4];
+  const int b = blockIdx.x;
+  const StepArg arg = args[b];
+  if (!arg.active) return;
+  begin_body<DD>(v, arg, *Kc, b, Sm, ybuf, zbuf, red);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Measurement update of the MFMA path, by orthogonal transformations only (the reference's square-root correction: QR of
 // (H L^-)^T, strategy_filter + correction_ts1, /root/reference/experiments/1_van_der_pol/vdp.py:64-65):
@@ -666,9 +674,13 @@ __device__ __forceinline__ void apply_all_panels(double (&X)[4 * DF], const doub
   }
 }
 
-template <int DT, int DD>
-__global__ __launch_bounds__(256, 2) void dense_correct_mfma_kernel(DenseView v, const StepArg* __restrict__ args,
-                                                                    const IwpConst* __restrict__ Kc) {
+// CTL (device-resident controller, pnode_advance_device): the tail of the kernel also takes the controller's decision for its
+// trajectory (controller_decision, pnode_common.hpp): no controller kernel between the attempts. (Running the first phase of the
+// NEXT attempt here as well -- two launches per attempt -- was measured and dropped: its serial Cholesky at two workgroups per CU
+// costs more than the begin kernel at four, 0.340 against 0.261 + 0.049 ms at B = 1024.)
+template <int DT, int DD, bool CTL>
+__global__ __launch_bounds__(256, 2) void dense_correct_mfma_kernel(DenseView v, StepArg* __restrict__ args, const IwpConst* __restrict__ Kc,
+                                                                    TrajCtl* __restrict__ ctl, ControlParams cp) {
   constexpr int D = 16 * DT, d = 16 * DD, W2 = 2 * d, LDF = W2 + 1, DF = W2 / 16, DCT = DF, DC = mfma_col_tiles(DT, DD);
   static_assert(DD <= 4, "one wavefront per 16-row strip of F; the pivot columns of a strip lie in the first super-tile");
   static_assert(DT % 4 == 0, "whole strips per wavefront");
@@ -683,10 +695,23 @@ __global__ __launch_bounds__(256, 2) void dense_correct_mfma_kernel(DenseView v,
   double* red = tv + W2;                  // [4]
   const int b = blockIdx.x;
   const StepArg arg = args[b];
-  if (!arg.active) return;
   const IwpConst& K = *Kc;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
+  if (!arg.active) {
+    if constexpr (CTL) {  // (a trajectory that sat this attempt out may still have to be started: the first round of a call)
+      if (tid == 0) {
+        TrajCtl c = ctl[b];
+        StepArg a = arg;
+        if (c.status == 0) {
+          controller_decision(c, a, 0.0, cp, true);
+          args[b] = a;
+          ctl[b] = c;
+        }
+      }
+    }
+    return;
+  }
   double p[kMaxN], pinv[kMaxN];
   precond_rt(v.n, arg.dt, K, p, pinv);
   const double p0 = p[0], p1 = p[1];
@@ -863,9 +888,19 @@ __global__ __launch_bounds__(256, 2) void dense_correct_mfma_kernel(DenseView v,
     part = wave_sum(part);
     if (lane == 0) red[wv] = part;
     __syncthreads();
+    const double enorm = sqrt((red[0] + red[1] + red[2] + red[3]) / double(d));
     if (tid == 0) {
-      v.errnorm[b] = sqrt((red[0] + red[1] + red[2] + red[3]) / double(d));
+      v.errnorm[b] = enorm;
       v.sigma[size_t(arg.dst) * sB + b] = v.sig_new[b];
+    }
+    if constexpr (CTL) {
+      if (tid == 0) {  // the controller's decision for this trajectory
+        TrajCtl c = ctl[b];
+        StepArg a = arg;
+        controller_decision(c, a, enorm, cp, false);
+        args[b] = a;
+        ctl[b] = c;
+      }
     }
   }
 }
@@ -877,7 +912,8 @@ bool dense_mfma_supported(const DenseView& v) {
 }
 
 template <int DT, int DD>
-static void launch_mfma(const DenseView& v, const StepArg* args, const IwpConst* K, hipStream_t s, const PhaseEvents* ev) {
+static void launch_mfma(const DenseView& v, const StepArg* args, const IwpConst* K, hipStream_t s, const PhaseEvents* ev,
+                        const FusedControl* fc) {
   auto mark = [&](int i) {
     if (ev) (void)hipEventRecord(ev->ev[i], s);
   };
@@ -895,11 +931,17 @@ static void launch_mfma(const DenseView& v, const StepArg* args, const IwpConst*
   (void)hipGetDevice(&dev);
   static bool attr1[64] = {};  // the opt-in to > 64 KB of dynamic LDS is per function AND per device
   if (!attr1[dev & 63]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_correct_mfma_kernel<DT, DD>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_correct_mfma_kernel<DT, DD, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, int(shm1));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_correct_mfma_kernel<DT, DD, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, int(shm1));
     attr1[dev & 63] = true;
   }
-  hipLaunchKernelGGL((dense_correct_mfma_kernel<DT, DD>), dim3(v.B), dim3(256), shm1, s, v, args, K);
+  if (fc)
+    hipLaunchKernelGGL((dense_correct_mfma_kernel<DT, DD, true>), dim3(v.B), dim3(256), shm1, s, v, fc->args, K, fc->ctl, fc->cp);
+  else
+    hipLaunchKernelGGL((dense_correct_mfma_kernel<DT, DD, false>), dim3(v.B), dim3(256), shm1, s, v, const_cast<StepArg*>(args), K,
+                       static_cast<TrajCtl*>(nullptr), ControlParams{});
   mark(4);
 }
 
@@ -911,12 +953,12 @@ void dense_launch_mfma_begin(const DenseView& v, const StepArg* args, const IwpC
 }
 
 void dense_launch_mfma_tail(const DenseView& v, const StepArg* args, const IwpConst* K, hipStream_t s,
-                            const PhaseEvents* ev) {
+                            const PhaseEvents* ev, const FusedControl* fc) {
   const int DT = v.D / 16, DD = v.d / 16;
-  if (DT == 8 && DD == 2) launch_mfma<8, 2>(v, args, K, s, ev);
-  else if (DT == 12 && DD == 2) launch_mfma<12, 2>(v, args, K, s, ev);
-  else if (DT == 16 && DD == 4) launch_mfma<16, 4>(v, args, K, s, ev);
-  else if (DT == 20 && DD == 4) launch_mfma<20, 4>(v, args, K, s, ev);
+  if (DT == 8 && DD == 2) launch_mfma<8, 2>(v, args, K, s, ev, fc);
+  else if (DT == 12 && DD == 2) launch_mfma<12, 2>(v, args, K, s, ev, fc);
+  else if (DT == 16 && DD == 4) launch_mfma<16, 4>(v, args, K, s, ev, fc);
+  else if (DT == 20 && DD == 4) launch_mfma<20, 4>(v, args, K, s, ev, fc);
 }
 
 }  // namespace pnode

@@ -102,13 +102,20 @@ void dense_launch_lq4(const DenseView& v, const StepArg* args, const IwpConst* K
 struct PhaseEvents {
   hipEvent_t ev[5];
 };
+// Device-resident controller fused into the step (MFMA path): the measurement-update kernel takes the controller's decision.
+struct FusedControl {
+  TrajCtl* ctl;
+  StepArg* args;  // device memory, read and written
+  ControlParams cp;
+};
+bool dense_fused_control_supported(const DenseView& v);
 void dense_launch_step(const DenseView& v, const StepArg* args, const IwpConst* K, hipStream_t s,
-                       const PhaseEvents* ev = nullptr);
+                       const PhaseEvents* ev = nullptr, const FusedControl* fc = nullptr);
 bool dense_mfma_supported(const DenseView& v);
 bool dense_state_factor_tiled(const DenseView& v);  // L in the register order of the strips (MFMA path) instead of row-major
 void dense_launch_mfma_begin(const DenseView& v, const StepArg* args, const IwpConst* K, hipStream_t s);
 void dense_launch_mfma_tail(const DenseView& v, const StepArg* args, const IwpConst* K, hipStream_t s,
-                            const PhaseEvents* ev);
+                            const PhaseEvents* ev, const FusedControl* fc = nullptr);
 void dense_launch_interp(const DenseView& v, const InterpArg* args, const IwpConst* K, hipStream_t s);
 void dense_launch_checkpoint_factors(const DenseView& v, const InterpArg* args, const StepArg* pargs, const IwpConst* K, hipStream_t s);
 // dense fixed-point smoother (generic kernels, pnode_dense_fp.hip)
