@@ -429,9 +429,9 @@ def main():
             flops = algorithmic_flops_lq(D, d) * B
             achieved = flops / (lq_ms * 1e-3) / 1e12
             # the north star also asks for the fraction of the HBM roofline: whole step (all dense kernels), algorithmic bytes
-            # (state factor read + written once, 2 * 8 * D^2 per trajectory) and the bytes the PMC pass measured
+            # (state factor read + written once, 2 * 8 * D (D - d) per trajectory) and the bytes the PMC pass measured
             step_ms = dev_ms / K
-            alg_bytes = 2.0 * 8.0 * D * D * B
+            alg_bytes = 2.0 * 8.0 * D * (D - d) * B  # state factor Ls (D x (D - d)) read once and written once
             meas_bytes = measured_traffic("dense_", B)
             hbm = {"peak_GBps": HBM_PEAK_GBS, "streaming_ceiling_GBps": 4000.0,
                    "streaming_ceiling_source": "scripts/hbm_probe.hip: read+write in the strip layout, no compute",

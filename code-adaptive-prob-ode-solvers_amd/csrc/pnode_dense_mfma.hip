@@ -608,7 +608,7 @@ __global__ __launch_bounds__(256) void dense_begin_mfma_kernel(DenseView v, cons
 // (every 16-row strip of L^- rotated by the reflector panels, which stay in LDS) is matrix-core streaming and fills the SIMDs
 // while the other workgroup of the CU is in its first half. (r03 also measured the two halves as two kernels -- the first with
 // 22 KB of LDS, the second with one or two workgroups per trajectory: 0.142 + 0.142 ms at B = 1024 against 0.31 for the r02
-// kernel; the chain kernel leaves the CUs idle, three of its workgroups do not fit the register file: git show 5a0f4f1^.)
+// kernel; the chain kernel leaves the CUs idle, three of its workgroups do not fit the register file: git show 7a66d4d.)
 // The 16-column tiles in which a panel is structurally zero are skipped (176 instead of 272 MFMAs per strip).
 // ---------------------------------------------------------------------------------------------------------------------
 
