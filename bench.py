@@ -376,7 +376,9 @@ def main():
         dist.all_reduce(bmax, op=dist.ReduceOp.MAX)
         pad = np.zeros((int(bmax.item()), d))
         pad[:B] = u_local  # shards differ by at most one trajectory: pad to equal shapes
-        gather_how = "rccl-ctypes"
+        # the path is agreed on by ALL ranks before anyone enters a collective (a rank that failed to create its communicator
+        # must not sit in a torch collective while the others sit in ncclAllGather)
+        comm, why = None, ""
         try:
             if backend != "nccl":
                 raise RuntimeError("rehearsal backend")
@@ -387,10 +389,20 @@ def main():
                 return box[0]
 
             comm = sharding.RcclGather(rank, world, local, exchange_id=via_group)
-            gathered = sharding.gather_results(pad, comm)
+        except Exception as e:
+            why = f"{type(e).__name__}: {e}"
+        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=tdev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        reasons = [None] * world
+        dist.all_gather_object(reasons, why)
+        if int(ok.item()) == 1:
+            gather_how = "rccl-ctypes"
+            gathered = sharding.gather_results(pad, comm)  # (a failure here ends the run with a non-zero exit)
             comm.close()
-        except Exception as e:  # keep the scaling run alive and say so in the line
-            gather_how = f"torch.distributed fallback ({type(e).__name__}: {e})"
+        else:
+            if comm is not None:
+                comm.close()
+            gather_how = "torch.distributed fallback on every rank (" + "; ".join(f"rank {i}: {w}" for i, w in enumerate(reasons) if w) + ")"
             t = torch.from_numpy(pad).to(tdev)
             outl = [torch.empty_like(t) for _ in range(world)]
             dist.all_gather(outl, t)

@@ -97,3 +97,20 @@ def solve_via_interpolate(method: str, vf, u0_like, /, save_at, *, dt0, atol, rt
 
 def solve_diffrax(method: str, vf, _u0_like, /, save_at, *, dt0, atol, rtol, ode_order=1):
     raise NotImplementedError("diffrax Runge-Kutta competitors are outside the hot-path scope (SURVEY.md section 2, row 3)")
+
+
+def asolve_scipy(method: str, vf, /, time_span, *, atol, rtol):
+    """Plot-quality truth from a scipy integrator (the reference's `asolve_scipy`, ivpsolvers.py:196-210: same signature, same
+    return value). Returns `solve_(u0: tuple, p) -> (t[K], y[K, d])` on scipy's own adaptive grid; host only, no GPU involved."""
+    import scipy.integrate
+
+    def solve_(u0: tuple, p):
+        if not isinstance(u0, tuple):
+            raise ValueError("Tuple expected.")
+        (y0,) = u0
+        res = scipy.integrate.solve_ivp(lambda t, y: np.asarray(vf(y, t=t, p=p)), time_span, np.asarray(y0, dtype=np.float64),
+                                        method=method, atol=atol, rtol=rtol)
+        return res.t, res.y.T
+
+    return solve_
+

@@ -343,6 +343,7 @@ def _save_every_step_smoother(vector_field, init, t0b, t1b, adaptive_solver, dt0
         if not active.any():
             break
         if np.any(count[active] >= max_steps):
+            batch.close()  # (the store of max_steps transitions is device memory: do not leave it to the garbage collector)
             raise RuntimeError(f"strategy_smoother stores every accepted step and max_steps={max_steps} is used up; "
                                "raise max_steps or use strategy_fixedpoint with solve_adaptive_save_at (fixed memory)")
         acc = loop.attempt(active, t1=t1b)

@@ -60,8 +60,8 @@ def main(argv=None):
     args = ap.parse_args(argv)
 
     vf, u0, tspan, params = ivps.rigid_body(time_span=(0.0, 50.0))
-    truth = scipy.integrate.solve_ivp(lambda t, y: vf(y, t=t, p=params), tspan, u0[0], method="LSODA", atol=1e-13, rtol=1e-13)
-    ts, ys = truth.t, truth.y.T
+    # plot-quality truth as the reference takes it (run_simple.py:22-24 -> ivpsolvers.asolve_scipy)
+    ts, ys = ivpsolvers.asolve_scipy("LSODA", vf, tspan, atol=1e-13, rtol=1e-13)(tuple(u0[:1]), params)
     n0, n1 = args.start, args.stop
     n1_short = n0 + (1 + n1 - n0) * 2 // 3
     tols = 0.1 ** np.arange(n0, n1, step=1.0)

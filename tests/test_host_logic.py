@@ -249,3 +249,17 @@ def test_two_rank_sharded_solve_and_gather_equals_single_process(tmp_path):
     assert np.array_equal(np.load(tmp_path / "steps.npy"), steps_ref)
 
 
+def test_asolve_scipy_reproduces_the_reference_truth_bit_for_bit(golden):
+    """odecheckpts.ivpsolvers.asolve_scipy (reference ivpsolvers.py:196-210) as run_simple.py:22-24 calls it: LSODA at 1e-13 on the
+    rigid body. The reference's committed data_ts / data_ys (subsampled in the fixture) are reproduced exactly."""
+    from odecheckpts import ivps, ivpsolvers
+
+    vf, u0, tspan, params = ivps.rigid_body(time_span=(0.0, 50.0))
+    ts, ys = ivpsolvers.asolve_scipy("LSODA", vf, tspan, atol=1e-13, rtol=1e-13)(tuple(u0[:1]), params)
+    g = golden["rigid_body"]
+    idx = np.searchsorted(ts, g["ts"])
+    assert ts.shape == (1992,) and ys.shape == (1992, 3)
+    assert np.array_equal(ts[idx], g["ts"]) and np.array_equal(ys[idx], g["ys"])
+    with pytest.raises(ValueError, match="Tuple expected"):
+        ivpsolvers.asolve_scipy("LSODA", vf, tspan, atol=1e-3, rtol=1e-3)(u0[0], params)
+
