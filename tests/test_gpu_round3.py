@@ -153,3 +153,34 @@ def test_one_launch_lq_soak_against_two_launch_lq(hip_lib):
     one.close()
     two.close()
     assert worst_e < 1e-6 and worst_m < 1e-9, (worst_e, worst_m)
+
+
+@pytest.mark.parametrize("N", [16, 32])
+def test_nan_member_on_the_mfma_path_stays_nan_and_leaves_its_neighbours_alone(hip_lib, N):
+    """A trajectory whose state is NaN must come back with a NaN error norm (the controller then stops it, like the reference,
+    SURVEY section 5: NaN is an expected result, not trapped) from the register-resident kernels too -- the sweep has no
+    reflection flag and guards its reciprocal square root with 1e-200, neither may swallow a NaN -- and the other members of the
+    batch must get the bits they get without it."""
+    nu, B = 3, 3
+    vf = V.brusselator(N)
+    y0 = np.stack([brusselator_y0(N, ph) for ph in (0.0, 0.4, 1.3)])
+    tc = np.stack(tcoeffs(vf, [y0], nu), axis=1)
+    bad = tc.copy()
+    bad[1, 0, 3] = np.nan
+    out = []
+    for init in (tc, bad):
+        bt = _batch(vf, nu, B)
+        bt.set_initial(init, np.zeros(B), np.ones(B))
+        bt.set_tolerances(1e-5, 1e-5)
+        err = np.zeros(B)
+        errs = []
+        for dt in (0.01, 0.02, 0.015):
+            bt.attempt_step(np.full(B, dt), np.ones(B, np.uint8), err)
+            bt.commit(np.ones(B, np.uint8))
+            errs.append(err.copy())
+        out.append((np.array(errs), bt.read_mean(0)))
+        bt.close()
+    (e_ok, m_ok), (e_bad, m_bad) = out
+    assert np.all(np.isnan(e_bad[:, 1])) and np.all(np.isnan(m_bad[1, 0]))
+    for b in (0, 2):
+        assert np.array_equal(e_ok[:, b], e_bad[:, b]) and np.array_equal(m_ok[b], m_bad[b])
