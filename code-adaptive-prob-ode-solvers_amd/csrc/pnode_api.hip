@@ -246,6 +246,7 @@ int pnode_create(const pnode_config* cfg, pnode_batch** out) {
     case PNODE_VF_PLEIADES_ORDER1: rc = need(d == 28 && k == 1, "pleiades (order 1): d=28"); break;
     case PNODE_VF_LOGISTIC: rc = need(k == 1 && cfg->num_vf_params == 2, "logistic: order 1, params [a,b]"); break;
     case PNODE_VF_LINEAR: rc = need(k == 1 && cfg->num_vf_params == 1, "linear: order 1, params [lam]"); break;
+    case PNODE_VF_THREE_BODY: rc = need(d == 2 && k == 2 && cfg->num_vf_params == 1, "restricted three-body problem: d=2, order 2, params [mu]"); break;
     case PNODE_VF_USER: rc = need(cfg->num_vf_params == 0, "user vector field: no device parameters"); break;
     default: rc = fail(PNODE_EINVAL, "unknown vf_id");
   }

@@ -2,7 +2,7 @@
 // Replaces the JAX callables + autodiff of /root/reference/src/odecheckpts/ivps.py:
 //   brusselator :124-156, van_der_pol :159-167 (and experiments/1_van_der_pol/vdp.py:52-54),
 //   rigid_body :20-29 (diffeqzoo defaults), _pleiades :66-99, pleiades_1st :44-56, logistic :8-17,
-//   first-order Van der Pol: experiments/old/7_node/node.py:23-37.
+//   first-order Van der Pol: experiments/old/7_node/node.py:23-37, three_body_restricted :32-41 (diffeqzoo's Arenstorf orbit).
 // Contract: y points at k*d doubles laid out [order][d] (y[i*d + b] = u^(i)_b), any address space.
 //   vf_f(c, y, a, t)          -> component a of f(u, ..., u^(k-1), t)
 //   vf_jac(c, y, a, i, b, t)  -> d f_a / d u^(i)_b
@@ -99,6 +99,14 @@ __device__ __forceinline__ double vf_f(const VfCtx& c, const double* y, int a, d
       return c.prm[0] * y[a] * (1.0 - c.prm[1] * y[a]);
     case PNODE_VF_LINEAR:
       return c.prm[0] * y[a];
+    case PNODE_VF_THREE_BODY: {
+      // rotating frame, y = [Y0, Y1, dY0, dY1]: Y'' = Y + 2 J dY - (1 - mu) (Y - P1) / |Y - P1|^3 - mu (Y - P2) / |Y - P2|^3
+      const double mu = c.prm[0], mp = 1.0 - mu;
+      const double x1 = y[0] + mu, x2 = y[0] - mp, yy = y[1];
+      const double r1 = x1 * x1 + yy * yy, r2 = x2 * x2 + yy * yy;
+      const double d1 = r1 * sqrt(r1), d2 = r2 * sqrt(r2);
+      return a == 0 ? y[0] + 2.0 * y[3] - mp * x1 / d1 - mu * x2 / d2 : yy - 2.0 * y[2] - mp * yy / d1 - mu * yy / d2;
+    }
     case PNODE_VF_USER:
       return c.uf[a];
     default:
@@ -155,6 +163,17 @@ __device__ __forceinline__ double vf_jac(const VfCtx& c, const double* y, int a,
       return a == b ? c.prm[0] * (1.0 - 2.0 * c.prm[1] * y[a]) : 0.0;
     case PNODE_VF_LINEAR:
       return a == b ? c.prm[0] : 0.0;
+    case PNODE_VF_THREE_BODY: {
+      if (i == 1) return a == b ? 0.0 : (a == 0 ? 2.0 : -2.0);  // Coriolis term
+      const double mu = c.prm[0], mp = 1.0 - mu;
+      const double x1 = y[0] + mu, x2 = y[0] - mp, yy = y[1];
+      const double r1 = x1 * x1 + yy * yy, r2 = x2 * x2 + yy * yy;
+      const double i13 = 1.0 / (r1 * sqrt(r1)), i23 = 1.0 / (r2 * sqrt(r2));
+      const double i15 = i13 / r1, i25 = i23 / r2;
+      if (a != b) return 3.0 * yy * (mp * x1 * i15 + mu * x2 * i25);
+      const double n1 = a == 0 ? x1 * x1 : yy * yy, n2 = a == 0 ? x2 * x2 : yy * yy;
+      return 1.0 - mp * (i13 - 3.0 * n1 * i15) - mu * (i23 - 3.0 * n2 * i25);
+    }
     case PNODE_VF_USER:
       return c.uj[size_t(a) * c.k * c.d + i * c.d + b];
     default:

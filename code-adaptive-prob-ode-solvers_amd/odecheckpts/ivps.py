@@ -55,7 +55,12 @@ def van_der_pol_first_order(mu=1.0):
 
 
 def three_body_restricted():
-    raise NotImplementedError("three_body_restricted is outside the benchmark configurations (SURVEY.md section 2, row 5)")
+    """Arenstorf orbit of the restricted three-body problem, second-order form (reference ivps.py:32-41, which takes the defaults
+    of diffeqzoo.ivps.three_body_restricted: the constants of Hairer, Norsett & Wanner; pinned by the reference's committed
+    experiments/5_vs_interpolation/data_solution.npy, tests/test_oracle_golden.py). Returns (vf, (u0, du0), time_span)."""
+    u0 = np.asarray([0.994, 0.0])
+    du0 = np.asarray([0.0, -2.00158510637908252240537862224])
+    return V.three_body_restricted(), (u0, du0), (0.0, 17.0652165601579625588917206249)
 
 
 def neural_ode_mlp(*, layer_sizes):

@@ -21,6 +21,7 @@ VF_PLEIADES_ORDER2 = 4
 VF_PLEIADES_ORDER1 = 5
 VF_LOGISTIC = 6
 VF_LINEAR = 7
+VF_THREE_BODY = 8
 VF_USER = 100
 
 
@@ -141,6 +142,17 @@ def _linear(vf, prm, y):
     return prm[0] * y
 
 
+def _three_body(vf, prm, y, dy):
+    """Restricted three-body problem in the rotating frame (Arenstorf orbit), second-order form; prm = (standardised moon mass,)."""
+    mu = prm[0]
+    mp = 1.0 - mu
+    y0, y1 = _split(y, 0, 1), _split(y, 1, 2)
+    v0, v1 = _split(dy, 0, 1), _split(dy, 1, 2)
+    d1 = ((y0 + mu) * (y0 + mu) + y1 * y1) ** 1.5
+    d2 = ((y0 - mp) * (y0 - mp) + y1 * y1) ** 1.5
+    return _concat([y0 + 2.0 * v1 - mp * (y0 + mu) / d1 - mu * (y0 - mp) / d2, y1 - 2.0 * v0 - mp * y1 / d1 - mu * y1 / d2])
+
+
 _EVAL = {
     VF_BRUSSELATOR: _brusselator,
     VF_VDP_ORDER2: _vdp2,
@@ -150,6 +162,7 @@ _EVAL = {
     VF_PLEIADES_ORDER1: _pleiades1,
     VF_LOGISTIC: _logistic,
     VF_LINEAR: _linear,
+    VF_THREE_BODY: _three_body,
 }
 
 
@@ -183,6 +196,11 @@ def logistic(a=1.0, b=1.0, d=1):
 
 def linear(lam, d=1):
     return VectorField(VF_LINEAR, d, 1, (float(lam),), "linear")
+
+
+def three_body_restricted(standardised_moon_mass=0.012277471):
+    """The IVP of the reference's experiment 5 (src/odecheckpts/ivps.py:32-41 -> diffeqzoo.ivps.three_body_restricted; d = 2, order 2)."""
+    return VectorField(VF_THREE_BODY, 2, 2, (float(standardised_moon_mass),), "three_body_restricted")
 
 
 @dataclasses.dataclass(frozen=True)

@@ -55,6 +55,7 @@ extern "C" {
 #define PNODE_VF_PLEIADES_ORDER1 5 /* ivps.py:44-56; d = 28, order 1; no params                       */
 #define PNODE_VF_LOGISTIC 6      /* ivps.py:8-17 (diffeqzoo logistic); d = 1, order 1; [a, b]         */
 #define PNODE_VF_LINEAR 7        /* test problem u' = lam * u (diagonal); d arbitrary; [lam]          */
+#define PNODE_VF_THREE_BODY 8    /* ivps.py:32-41 (diffeqzoo three_body_restricted, experiment 5); d = 2, order 2; [moon mass] */
 
 /* Escape hatch for vector fields that are not built in: the HOST evaluates f (and, for correction_ts1, the Jacobian)
  * for the whole batch at the extrapolated means and hands the values over before each attempt

@@ -25,7 +25,7 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden():
     d = os.path.join(ROOT, "tests", "golden")
-    return {name: np.load(os.path.join(d, f"{name}.npz")) for name in ("vdp", "brusselator", "rigid_body", "pleiades")}
+    return {name: np.load(os.path.join(d, f"{name}.npz")) for name in ("vdp", "brusselator", "rigid_body", "pleiades", "three_body")}
 
 
 @pytest.fixture(scope="session")

@@ -12,6 +12,8 @@ Sources (all are outputs of the real JAX/probdiffeq path, committed in the refer
   experiments/2_workprec_simple/data_ts.npy, data_ys.npy (rigid body truth)      (run_simple.py:22-24)
   experiments/3_workprec_harder/data_ts.npy, data_ys.npy (Pleiades truth)        (run_harder.py:22-24)
   experiments/{2,3}_*/data_results.npy  precision / work arrays                  (run_simple.py:208-215)
+  experiments/5_vs_interpolation/data_solution.npy  filter solution at every accepted step, restricted three-body problem
+                                                    (measure.py:155-163,211-232); data_results.npy "No. steps" (measure.py:177-199)
 
 The dict-valued .npy files hold pickled jax.Array objects. They are read with a WHITELIST
 unpickler: only numpy globals plus a stub for jax._src.array._reconstruct_array are allowed.
@@ -112,7 +114,21 @@ def main():
         np.savez_compressed(f"{OUT}/{tag}.npz", **flat)
         print(tag, {k: v.shape for k, v in flat.items()})
 
-    for name in ("vdp.npz", "brusselator.npz", "rigid_body.npz", "pleiades.npz"):
+    # --- Restricted three-body problem (isotropic TS0, ode_order 2, uncalibrated solver) -----
+    d5 = f"{REF}/5_vs_interpolation"
+    res5 = load_object_npy(f"{d5}/data_results.npy")
+    steps = {}
+    for row in res5.values():  # the nine rows repeat three tolerances
+        tol = {"$10^{-4}$": 1e-4, "$10^{-7}$": 1e-7, "$10^{-10}$": 1e-10}[row["Tolerance"]]
+        steps[tol] = int(row["No. steps"].replace(",", ""))
+    np.savez_compressed(
+        f"{OUT}/three_body.npz",
+        baseline_solution=f64(np.load(f"{d5}/data_solution.npy")),  # nu = 3, filter, tol 1e-7, every accepted step (measure.py:163)
+        smoother_tols=f64(sorted(steps, reverse=True)),
+        smoother_num_steps=np.asarray([steps[t] for t in sorted(steps, reverse=True)], dtype=np.int64),  # nu = 4 (measure.py:177-181)
+    )
+
+    for name in ("vdp.npz", "brusselator.npz", "rigid_body.npz", "pleiades.npz", "three_body.npz"):
         print(name, os.path.getsize(f"{OUT}/{name}") // 1024, "KB")
 
 

@@ -184,3 +184,70 @@ def test_nan_member_on_the_mfma_path_stays_nan_and_leaves_its_neighbours_alone(h
     assert np.all(np.isnan(e_bad[:, 1])) and np.all(np.isnan(m_bad[1, 0]))
     for b in (0, 2):
         assert np.array_equal(e_ok[:, b], e_bad[:, b]) and np.array_equal(m_ok[b], m_bad[b])
+
+
+def _three_body(nu, strategy="filter", model="isotropic", corr="ts0"):
+    from odecheckpts import ivps
+    from probdiffeq_hip import ivpsolve, ivpsolvers, taylor
+    from probdiffeq_hip.impl import impl
+
+    vf, (u0, du0), (t0, t1) = ivps.three_body_restricted()
+    impl.select(model, ode_shape=(2,))
+    correction = (ivpsolvers.correction_ts0 if corr == "ts0" else ivpsolvers.correction_ts1)(ode_order=2)
+    strat = getattr(ivpsolvers, f"strategy_{strategy}")(ivpsolvers.prior_ibm(num_derivatives=nu), correction)
+    solver = ivpsolvers.solver(strat)  # uncalibrated, as experiment 5 builds it (measure.py:47, 100, 215)
+    tcs = taylor.odejet_padded_scan(vf, [u0, du0], num=nu + 1 - 2)
+    return vf, solver, solver.initial_condition(tcs, 1.0), t0, t1, ivpsolve
+
+
+def test_three_body_baseline_solution_of_experiment_5_through_api(hip_lib, golden):
+    """The reference's experiment-5 baseline (measure.py:155-163, 211-232; committed as data_solution.npy: the filter's mean at every
+    accepted step of the Arenstorf orbit) through the public API on the GPU: the same 7 540 accepted steps, every value within 1e-9."""
+    ref = golden["three_body"]["baseline_solution"]
+    vf, solver, init, t0, t1, ivpsolve = _three_body(3)
+    asolver = ivpsolve.adaptive(solver, atol=1e-7, rtol=1e-7, control=ivpsolve.control_proportional_integral())
+    sol = ivpsolve.solve_adaptive_save_every_step(vf, init, t0=t0, t1=t1, dt0=0.01, adaptive_solver=asolver)
+    assert sol.u.shape == ref.shape == (7541, 2)
+    assert np.max(np.abs(sol.u - ref)) < 1e-9
+
+
+@pytest.mark.parametrize("k,strategy", [(0, "smoother"), (1, "smoother"), (2, "filter")])
+def test_three_body_step_counts_of_experiment_5_through_api(hip_lib, golden, k, strategy):
+    """'No. steps' of experiment 5 (measure.py:177-199: nu = 4, the AS runner = strategy_smoother + solve_adaptive_save_every_step):
+    448 / 2 570 / 14 469 accepted steps at tol 1e-4 / 1e-7 / 1e-10, bit-exact (the tightest through the filter: the decisions are
+    the smoother's, without 14 469 stored transitions)."""
+    g = golden["three_body"]
+    tol, want = float(g["smoother_tols"][k]), int(g["smoother_num_steps"][k])
+    vf, solver, init, t0, t1, ivpsolve = _three_body(4, strategy)
+    asolver = ivpsolve.adaptive(solver, atol=tol, rtol=tol, control=ivpsolve.control_proportional_integral())
+    sol = ivpsolve.solve_adaptive_save_every_step(vf, init, t0=t0, t1=t1, dt0=0.01, adaptive_solver=asolver)
+    assert len(sol.t) - 1 == want and sol.t[-1] == t1
+
+
+def test_three_body_analytic_jacobian_on_the_device(hip_lib):
+    """correction_ts1 on the restricted three-body problem (dense model, D = 8: the fused one-wavefront kernel and the generic
+    kernels): single steps against the oracle, whose Jacobian is a complex-step derivative of the NumPy vector field."""
+    from odecheckpts import ivps
+
+    vf, (u0, du0), _ = ivps.three_body_restricted()
+    nu, B = 3, 1
+    tc = tcoeffs(vf, [u0[None], du0[None]], nu)
+    cfg = po.SolverConfig(nu=nu, model="dense", correction="ts1", strategy="filter", calibration="dynamic")
+    prob = oracle_problem(vf)
+    for generic in (False, True):
+        bt = _backend.Batch(batch=B, d=2, nu=nu, ode_order=2, model="dense", correction="ts1", strategy="filter", calibration="dynamic",
+                            vf_id=vf.vf_id, vf_params=vf.param_array(), num_checkpoints=2)
+        if generic:
+            bt.set_generic_path(True)
+        bt.set_initial(np.stack(tc, axis=1), np.zeros(B), np.ones(B))
+        bt.set_tolerances(1e-6, 1e-6)
+        st = po.initial_state(cfg, [c[0] for c in tc], 0.0)
+        err = np.zeros(B)
+        for dt in (1e-3, 2e-3, 2e-3):
+            bt.attempt_step(np.full(B, dt), np.ones(B, np.uint8), err)
+            bt.commit(np.ones(B, np.uint8))
+            e, st = po.step(cfg, prob, st, dt)
+            en = po.normalise_error(po.AdaptiveConfig(1e-6, 1e-6), e, st.mean[0], st.mean[0])
+            assert abs(err[0] - en) <= 1e-7 * en
+            assert relmax(bt.read_mean(0)[0], np.stack(st.mean)) < 1e-9
+        bt.close()

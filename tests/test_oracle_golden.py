@@ -154,3 +154,37 @@ def test_config1_van_der_pol_mu1_oracle_against_scipy():
         assert np.allclose(u, truth, atol=1e-3, rtol=1e-3)
         assert np.max(np.abs(u - truth)) < 1e-4  # (2e-6 .. 3e-6 in practice)
         assert 300 < int(sol.num_steps[-1]) < 600
+
+
+def _three_body_setup(nu):
+    from odecheckpts import ivps
+
+    vf, (u0, du0), (t0, t1) = ivps.three_body_restricted()
+    cfg = po.SolverConfig(nu=nu, model="isotropic", correction="ts0", strategy="filter", calibration="none")
+    tc = tcoeffs(vf, [u0, du0], nu)
+    return vf, cfg, tc, t0, t1
+
+
+def test_three_body_baseline_solution_of_experiment_5(golden):
+    """Experiment 5's baseline (measure.py:155-163, 211-232): restricted three-body problem (Arenstorf orbit, second-order form),
+    isotropic EKF0, nu = 3, strategy_filter, the UNCALIBRATED solver (ivpsolvers.solver, output scale 1), tol 1e-7, dt0 0.01,
+    solve_adaptive_save_every_step. The reference committed the solution at every accepted step (data_solution.npy): the oracle
+    takes exactly the same 7 540 steps and agrees to 2.2e-10 over the whole orbit. Pins ode_order = 2, the uncalibrated solver, the
+    PI controller on a second problem, and the IVP's constants (diffeqzoo is not installed)."""
+    ref = golden["three_body"]["baseline_solution"]
+    vf, cfg, tc, t0, t1 = _three_body_setup(3)
+    sol = po.solve_adaptive_save_every_step(cfg, po.AdaptiveConfig(1e-7, 1e-7), oracle_problem(vf), po.initial_state(cfg, tc, t0), t1, 0.01)
+    assert sol.u.shape == ref.shape == (7541, 2)
+    dev = np.max(np.abs(sol.u - ref), axis=1)
+    assert np.max(dev[:1000]) < 1e-12 and np.max(dev) < 1e-9
+
+
+@pytest.mark.parametrize("k", [0, 1, 2])
+def test_three_body_step_counts_of_experiment_5(golden, k):
+    """The 'No. steps' column of experiment 5 (measure.py:177-199: nu = 4, solve_adaptive_save_every_step at tol 1e-4, 1e-7, 1e-10,
+    448 / 2 570 / 14 469 accepted steps; the smoother's forward pass takes the filter's decisions): bit-exact."""
+    g = golden["three_body"]
+    tol, want = float(g["smoother_tols"][k]), int(g["smoother_num_steps"][k])
+    vf, cfg, tc, t0, t1 = _three_body_setup(4)
+    sol = po.solve_adaptive_save_every_step(cfg, po.AdaptiveConfig(tol, tol), oracle_problem(vf), po.initial_state(cfg, tc, t0), t1, 0.01)
+    assert len(sol.t) - 1 == want
