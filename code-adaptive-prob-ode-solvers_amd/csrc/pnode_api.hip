@@ -1210,15 +1210,16 @@ int pnode_offgrid_means(pnode_batch* h, const int32_t* num_filled, const double*
   return PNODE_OK;
 }
 
-int pnode_sample_checkpoints(pnode_batch* h, const int32_t* num_filled, int32_t num_samples, const double* eps, double* out) {
-  if (!h || !num_filled || !eps || !out || num_samples < 1) return fail(PNODE_EINVAL, "bad argument");
+int pnode_sample_checkpoints_n(pnode_batch* h, const int32_t* num_filled, int32_t num_points, int32_t num_samples, const double* eps,
+                               double* out) {
+  if (!h || !num_filled || !eps || !out || num_samples < 1 || num_points < 1) return fail(PNODE_EINVAL, "bad argument");
   if (h->dense || !h->iso.fixedpoint)
     return fail(PNODE_EINVAL, "posterior sampling needs the isotropic model with a stored backward model (smoother / fixedpoint)");
   HIP_TRY(hipSetDevice(h->cfg.device));
-  const size_t B = h->cfg.batch, K = h->cfg.num_checkpoints, S = size_t(num_samples), nd = size_t(h->n) * h->cfg.d;
+  const size_t B = h->cfg.batch, K = h->cfg.num_checkpoints, S = size_t(num_samples), P = size_t(num_points), nd = size_t(h->n) * h->cfg.d;
   for (size_t b = 0; b < B; ++b)
-    if (num_filled[b] < 0 || size_t(num_filled[b]) > K) return fail(PNODE_EINVAL, "num_filled out of range");
-  const size_t cnt = B * S * (K + 1) * nd;
+    if (num_filled[b] < 0 || size_t(num_filled[b]) > K || size_t(num_filled[b]) + 1 > P) return fail(PNODE_EINVAL, "num_filled out of range");
+  const size_t cnt = B * S * P * nd;
   double *dEps = nullptr, *dOut = nullptr;
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&dEps), cnt * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&dOut), cnt * sizeof(double));
@@ -1226,7 +1227,7 @@ int pnode_sample_checkpoints(pnode_batch* h, const int32_t* num_filled, int32_t 
   if (e == hipSuccess) e = hipMemcpyAsync(dEps, eps, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(h->dFilled, num_filled, B * sizeof(int32_t), hipMemcpyHostToDevice, h->stream);
   if (e == hipSuccess) {
-    iso_launch_sample(h->iso, h->dFilled, int(S), dEps, dOut, h->stream);
+    iso_launch_sample(h->iso, h->dFilled, int(S), int(P), dEps, dOut, h->stream);
     e = hipMemcpyAsync(out, dOut, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream);
   }
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
@@ -1235,6 +1236,11 @@ int pnode_sample_checkpoints(pnode_batch* h, const int32_t* num_filled, int32_t 
   (void)hipFree(dOut);
   if (e != hipSuccess) return fail(PNODE_EDEVICE, hipGetErrorString(e));
   return PNODE_OK;
+}
+
+int pnode_sample_checkpoints(pnode_batch* h, const int32_t* num_filled, int32_t num_samples, const double* eps, double* out) {
+  if (!h) return fail(PNODE_EINVAL, "bad argument");
+  return pnode_sample_checkpoints_n(h, num_filled, h->cfg.num_checkpoints + 1, num_samples, eps, out);
 }
 
 int pnode_last_step_ms(pnode_batch* h, float* ms_out) {

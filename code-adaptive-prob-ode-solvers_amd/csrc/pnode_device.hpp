@@ -35,7 +35,7 @@ void iso_launch_advance(const IsoView& v, TrajCtl* ctl, const IwpConst* K, const
 void iso_launch_smooth(const IsoView& v, const int32_t* num_filled, double* out, hipStream_t s);
 void iso_launch_offgrid(const IsoView& v, const OffgridArg* qs, int Q, const double* init, const double* smoothed, const IwpConst* K,
                         double* out, hipStream_t s);
-void iso_launch_sample(const IsoView& v, const int32_t* num_filled, int S, const double* eps, double* out, hipStream_t s);
+void iso_launch_sample(const IsoView& v, const int32_t* num_filled, int S, int P, const double* eps, double* out, hipStream_t s);
 
 // Dense model (EKF1 / EKF0 with a full D x D factor), D = n*d.
 struct DenseView {

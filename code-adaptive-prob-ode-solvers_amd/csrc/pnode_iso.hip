@@ -766,7 +766,7 @@ __global__ __launch_bounds__(256) void iso_offgrid_kernel(IsoView v, const Offgr
 // eps / out: [B][S][K+1][n][d] (entry 0 = initial time, entry c+1 = store entry c); the host supplies the standard-normal base
 // samples, so a run is reproducible against the oracle. One wavefront per (trajectory, sample).
 template <int N>
-__global__ __launch_bounds__(256) void iso_sample_kernel(IsoView v, const int32_t* __restrict__ num_filled, int S,
+__global__ __launch_bounds__(256) void iso_sample_kernel(IsoView v, const int32_t* __restrict__ num_filled, int S, int P,
                                                          const double* __restrict__ eps, double* __restrict__ out) {
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
@@ -776,8 +776,8 @@ __global__ __launch_bounds__(256) void iso_sample_kernel(IsoView v, const int32_
   const int nf = num_filled[b];
   if (nf <= 0) return;
   const int d = v.d;
-  const double* e = eps + size_t(item) * (v.K + 1) * N * d;
-  double* o = out + size_t(item) * (v.K + 1) * N * d;
+  const double* e = eps + size_t(item) * P * N * d;  // P points per sample (>= num_filled + 1): the caller's stride, not the store's capacity
+  double* o = out + size_t(item) * P * N * d;
   double RT[N][N];
   load_small<N>(v.ck_fac + (size_t(b) * v.K + nf - 1) * N * N, RT);
   for (int j = lane; j < d; j += kWave) {
@@ -897,9 +897,9 @@ void iso_launch_offgrid(const IsoView& v, const OffgridArg* qs, int Q, const dou
   PNODE_DISPATCH_N(v.n, CALL)
 #undef CALL
 }
-void iso_launch_sample(const IsoView& v, const int32_t* num_filled, int S, const double* eps, double* out, hipStream_t s) {
+void iso_launch_sample(const IsoView& v, const int32_t* num_filled, int S, int P, const double* eps, double* out, hipStream_t s) {
   const int blocks = (v.B * S + 3) / 4;
-#define CALL(NN) hipLaunchKernelGGL((iso_sample_kernel<NN>), dim3(blocks), dim3(256), 0, s, v, num_filled, S, eps, out)
+#define CALL(NN) hipLaunchKernelGGL((iso_sample_kernel<NN>), dim3(blocks), dim3(256), 0, s, v, num_filled, S, P, eps, out)
   PNODE_DISPATCH_N(v.n, CALL)
 #undef CALL
 }

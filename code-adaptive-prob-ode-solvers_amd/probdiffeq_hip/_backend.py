@@ -24,7 +24,7 @@ SYMBOLS = (
     "pnode_set_tolerances pnode_attempt_step pnode_user_extrapolate pnode_user_set_vf pnode_commit pnode_interpolate pnode_checkpoint_at_step "
     "pnode_solve_fixed_grid pnode_solve_adaptive_save_at pnode_solve_adaptive_save_at_device pnode_read_mean pnode_read_time pnode_read_output_scale pnode_read_factor "
     "pnode_read_checkpoint_means pnode_read_checkpoint_factors pnode_smooth_checkpoint_means pnode_last_step_ms pnode_set_phase_timing "
-    "pnode_last_phase_ms pnode_set_generic_path pnode_stream pnode_advance_device pnode_debug_set_lq_spin_limit pnode_phase_ms_mean"
+    "pnode_last_phase_ms pnode_set_generic_path pnode_stream pnode_advance_device pnode_debug_set_lq_spin_limit pnode_phase_ms_mean pnode_sample_checkpoints_n"
 ).split()
 
 
@@ -120,6 +120,7 @@ def load_library():
     lib.pnode_stream.argtypes = [vp]
     lib.pnode_offgrid_means.argtypes = [vp, i32p, dp, C.c_int32, dp, dp, dp, i32p, u8p, dp]
     lib.pnode_sample_checkpoints.argtypes = [vp, i32p, C.c_int32, dp, dp]
+    lib.pnode_sample_checkpoints_n.argtypes = [vp, i32p, C.c_int32, C.c_int32, dp, dp]
     lib.pnode_advance_device.argtypes = [vp, dp, dp, dp, C.POINTER(PnodeControl), C.c_double, C.c_int32, i32p, i64p]
     lib.pnode_stream.restype = vp
     for name in SYMBOLS:
@@ -370,13 +371,15 @@ class Batch:
         return out
 
     def sample_checkpoints(self, num_filled, eps):
-        """Joint posterior samples (B, S, K+1, n, d) from base samples eps of the same shape (pnode_sample_checkpoints)."""
+        """Joint posterior samples (B, S, P, n, d) from base samples eps of the same shape; P >= max(num_filled) + 1 points per
+        sample (pnode_sample_checkpoints_n; P = K + 1 is the store's capacity)."""
         nf = self._slots(num_filled)
         eps = _f64(eps)
-        if eps.ndim != 5 or eps.shape[0] != self.B or eps.shape[2:] != (self.K + 1, self.n, self.d):
-            raise ValueError(f"eps must have shape ({self.B}, S, {self.K + 1}, {self.n}, {self.d})")
+        if eps.ndim != 5 or eps.shape[0] != self.B or eps.shape[3:] != (self.n, self.d) or eps.shape[2] < int(nf.max()) + 1:
+            raise ValueError(f"eps must have shape ({self.B}, S, P >= {int(nf.max()) + 1}, {self.n}, {self.d})")
         out = np.zeros_like(eps)
-        _check(self._lib.pnode_sample_checkpoints(self._h, nf.ctypes.data_as(C.POINTER(C.c_int32)), eps.shape[1], _dp(eps), _dp(out)))
+        _check(self._lib.pnode_sample_checkpoints_n(self._h, nf.ctypes.data_as(C.POINTER(C.c_int32)), eps.shape[2], eps.shape[1],
+                                                    _dp(eps), _dp(out)))
         return out
 
     def set_generic_path(self, enabled=True):

@@ -425,16 +425,42 @@ def solve_adaptive_save_every_step(vector_field, initial_condition: InitialCondi
     return sols if init.batched else sols[0]
 
 
+def _fixed_grid_smoother(vector_field, init, gb, solver, device):
+    """strategy_smoother on a prescribed grid (experiments/5_vs_interpolation/measure.py:129-140: the 'textbook' runner re-solves
+    on the union of its adaptive grid and save_at): every step is stored with its backward transition, the solution is the
+    backward pass over all of them; `solution.posterior` feeds stats.markov_sample. Isotropic model (the store is the fixed-point
+    kernels' without the merge), one host round trip per step."""
+    B, G = gb.shape
+    if np.any(np.diff(gb, axis=1) <= 0):
+        raise ValueError("grid must be strictly increasing")
+    batch = _make_batch(vector_field, init, solver, G - 1, device)
+    batch.set_initial(init.tcoeffs, np.ascontiguousarray(gb[:, 0]), init.output_scale)
+    err, one = np.zeros(B), np.ones(B, np.uint8)
+    count = np.zeros(B, dtype=np.int64)
+    for g in range(1, G):
+        batch.attempt_step(np.ascontiguousarray(gb[:, g] - gb[:, g - 1]), one, err)
+        batch.commit(one)
+        batch.checkpoint_at_step(count)
+        count = count + 1
+    means = batch.smooth_checkpoint_means(count.astype(np.int32))
+    scale = batch.read_output_scale(0)
+    sols = []
+    for b in range(B):
+        m = means[b, :G].copy()
+        post = Posterior(m[None], "smoother", batch, gb.copy(), count.astype(np.int32), init.tcoeffs, b)
+        sols.append(Solution(gb[b].copy(), m[:, 0, :], post, scale[b], np.arange(G), G - 1))
+    return sols if init.batched else sols[0]
+
+
 def solve_fixed_grid(vector_field, initial_condition: InitialCondition, grid, solver: Solver, *, device=None) -> Solution:
     """Pure predict/correct loop on a prescribed grid, no controller (vdp.py:88-103). All launches are
     enqueued on the device stream without host synchronisation. grid: (G,) shared or (B, G)."""
-    if solver.strategy.kind == "smoother":
-        raise NotImplementedError("solve_fixed_grid is implemented for strategy_filter / strategy_fixedpoint; a smoother solve "
-                                  "goes through solve_adaptive_save_every_step")
     init = initial_condition
     B, n, d = init.tcoeffs.shape
     grid = np.asarray(grid, dtype=np.float64)
     gb = np.broadcast_to(grid, (B, grid.shape[-1]))
+    if solver.strategy.kind == "smoother":
+        return _fixed_grid_smoother(vector_field, init, np.ascontiguousarray(gb), solver, device)
     batch = _make_batch(vector_field, init, solver, 0, device)
     batch.set_initial(init.tcoeffs, np.ascontiguousarray(gb[:, 0]), init.output_scale)
     u = batch.solve_fixed_grid(grid if grid.ndim == 1 else np.ascontiguousarray(gb))

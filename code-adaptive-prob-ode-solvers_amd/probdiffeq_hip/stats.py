@@ -95,7 +95,8 @@ def markov_sample(key, markov_seq: MarkovSeq, *, shape=(), reverse: bool = True)
     shape = tuple(int(s) for s in np.atleast_1d(shape)) if np.size(shape) else ()
     S = int(np.prod(shape)) if shape else 1
     rng = key if isinstance(key, np.random.Generator) else np.random.default_rng(key)
-    eps = rng.standard_normal((batch.B, S, batch.K + 1, batch.n, batch.d))
+    # (sized by the entries the solve filled, not by the store's capacity: a store-every-step smoother holds up to 16 384)
+    eps = rng.standard_normal((batch.B, S, int(np.max(nf)) + 1, batch.n, batch.d))
     out = batch.sample_checkpoints(nf, eps)
     which = list(range(batch.B)) if post.index is None else [post.index]
     if len({int(nf[b]) for b in which}) != 1:

@@ -205,6 +205,10 @@ int pnode_offgrid_means(pnode_batch* h, const int32_t* num_filled, const double*
  * eps: standard-normal base samples [B][S][K+1][nu+1][d] from the caller (entry 0 = initial time, entry c+1 = store entry c);
  * out: the samples, same layout. */
 int pnode_sample_checkpoints(pnode_batch* h, const int32_t* num_filled, int32_t num_samples, const double* eps, double* out);
+/* The same with eps / out of num_points (>= max num_filled + 1) entries per sample instead of the store's capacity K + 1: a
+ * store-every-step smoother has a capacity of thousands of entries of which a solve fills a few hundred. */
+int pnode_sample_checkpoints_n(pnode_batch* h, const int32_t* num_filled, int32_t num_points, int32_t num_samples, const double* eps,
+                               double* out);
 
 /* Timing of the device work of the most recent attempt_step (HIP events on the handle's stream),
  * in milliseconds; used by bench.py for the roofline line. Needs pnode_set_phase_timing(h, 1). */

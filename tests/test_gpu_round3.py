@@ -251,3 +251,32 @@ def test_three_body_analytic_jacobian_on_the_device(hip_lib):
             assert abs(err[0] - en) <= 1e-7 * en
             assert relmax(bt.read_mean(0)[0], np.stack(st.mean)) < 1e-9
         bt.close()
+
+
+def test_experiment_5_script_reproduces_the_reference_step_counts_and_schema(hip_lib, golden):
+    """experiments/vs_interpolation.py = the reference's experiment 5 (measure.py:153-209) through the public API: fixed-point
+    solver + save_at + markov_sample against smoother + fixed grid (the union of its adaptive grid and save_at) + markov_sample.
+    The result dict has the reference's keys, 'No. steps' equals the reference's committed 448 / 2,570 / 14,469, and the two routes
+    to the sample mean agree at the save_at points."""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("vs_interpolation", os.path.join(root, "experiments", "vs_interpolation.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    results, baseline = mod.main(["--samples", "5", "--nosave"])
+    g = golden["three_body"]
+    assert np.max(np.abs(baseline.u - g["baseline_solution"])) < 1e-9
+    assert [results[i]["No. steps"] for i in (1, 2, 3)] == [f"{int(n):,}" for n in g["smoother_num_steps"]]
+    assert set(results[1]) == {"No. Samples", "Tolerance", "No. steps", "Time (s): AS", "Time (s): ATS (ours)"}
+    # the two routes sample the same posterior family: their sample means at the save_at points agree to the solvers' accuracy
+    from odecheckpts import ivps
+
+    vf, inits, tspan = ivps.three_body_restricted()
+    save_at = np.linspace(tspan[0], tspan[1])
+    ats, _ = mod.checkpoint_runner(vf, inits, tspan, 200)(1e-7, save_at)
+    grid_of, text = mod.textbook_runner(vf, inits, tspan, 200)
+    as_, _ = text(np.union1d(grid_of(1e-7, save_at), save_at), save_at)
+    assert ats.shape == as_.shape == (50, 2)
+    assert np.max(np.abs(ats - as_)) < 1e-3

@@ -145,10 +145,12 @@ def test_solver_construction_and_errors():
     assert strat.model == "isotropic"
     with pytest.raises(TypeError):
         ivpsolve.solve_fixed_grid(lambda y, t: y, init, grid=np.linspace(0, 1, 3), solver=solver)
+    # strategy_smoother on a fixed grid exists for the isotropic model (the reference's use, measure.py:129-140); a grid that is
+    # not increasing is refused before a device is touched
     smoother = ivpsolvers.solver_dynamic(ivpsolvers.strategy_smoother(prior, ivpsolvers.correction_ts0()))
-    with pytest.raises((NotImplementedError, ValueError)):
+    with pytest.raises(ValueError):
         ivpsolve.solve_fixed_grid(V.linear(-1.0, d=4), smoother.initial_condition([np.ones(4)] * 4),
-                                  grid=np.linspace(0, 1, 3), solver=smoother)
+                                  grid=np.array([0.0, 0.5, 0.5]), solver=smoother)
     with pytest.raises(ValueError):
         ivpsolve.adaptive(solver, norm_ord=1)
 
