@@ -5,7 +5,7 @@
 //   * A wavefront holds one 16-row strip of Mt (full width) in registers, a group one 64-row block. In pass P the panel group
 //     holds block P: wavefront j applies the panels 0 .. j-1 of the pass as they are published, factorises its own strip in
 //     registers (pnode_lq_sweep.hpp: DPP-operand FMAs, no LDS, no barrier) and publishes it as panel j (V = [e ; scl x], the
-//     compact-WY factor and the scales, in LDS slot j). The other group holds block P + 1 and applies every panel the moment it
+//     compact-WY factor and the scales, in an LDS slot). The other group holds block P + 1 and applies every panel the moment it
 //     is published, so that ITS chain (pass P + 1) starts as soon as panel 3 is applied -- beside the remaining updates of pass P,
 //     which the wavefronts of the former panel group stream as they come free (strip j of the blocks P + 3 .. back to HBM, strip j
 //     of block P + 2 last: it is kept and is that wavefront's panel in pass P + 2).
@@ -13,12 +13,19 @@
 //     D = 256 only one 64-row block makes one round trip through HBM (none at D <= 192).
 //   * Persistent workgroups, one per CU: each walks over the trajectories blockIdx.x, blockIdx.x + gridDim.x, .. and the passes
 //     of consecutive trajectories form ONE sequence (global pass G = NBLK it + P): group A loads and factorises block 0 of the
-//     next trajectory while group B is still in the last pass of the current one.
-//   * No workgroup barrier after the prologue. pubS[k] = G + 1: panel k of global pass G is in LDS; doneS[8 k + w] = G: wavefront w
-//     will not read slot k of any pass < G again (the writer of pass G waits for all eight; per-wavefront words, not a shared
-//     counter: a wavefront may be done with a slot of the running pass before the slowest one is done with the previous pass);
-//     storedS[j]: strip j of the blocks parked in HBM by pass G. Every wait is a bounded spin (a wavefront that runs into the
-//     limit raises the abort word, all waits then fall through and the outputs of the trajectory are NaN).
+//     next trajectory while group B is still in the last pass of the current one -- one panel BEHIND it: the wavefronts j of the
+//     two groups share SIMD j, two sweeps side by side on one SIMD take twice as long, so the chain of the first pass works on
+//     SIMD j only once the chain of the last pass has left it (`follows` below).
+//   * FIVE LDS slots for the four panels of a pass: panel j of global pass G has the sequence number n = 4 G + j and lives in slot
+//     n % 5, so that the first panel of a pass does not wait for the last trailing update of the pass before.
+//   * No workgroup barrier after the prologue. pubS[s] = n + 1: panel n is in slot s; nextS[w] = n: wavefront w will not read a
+//     panel with a sequence number < n again (the writer of panel n waits until all eight are beyond n - 5; per-wavefront words,
+//     not a shared counter); storedS[j]: strip j of the blocks parked in HBM by pass G. Every wait is a bounded spin (a wavefront
+//     that runs into the limit reports it in the handle's fault words and raises the abort word, all waits then fall through,
+//     the outputs of the trajectory are NaN and the API call returns PNODE_EDEVICE).
+//   * scripts/lq_timeline.py (diagnostic build) prints when every panel of a trajectory arrived at its sweep, was swept, had its
+//     slot and was published: what is left beside the chain are collisions of the chain's wavefront with the trailing MFMAs of
+//     the other wavefront of its SIMD (profiles/r03_lq_timeline.txt).
 //   * (A column-split variant -- four wavefronts sweeping a quarter of the columns each -- was measured and dropped: an LDS
 //     round trip costs 300-400 cycles under load, so the per-pivot exchange of the partial dot products, 850 cycles, outweighs
 //     the four times shorter DPP sweep.)
@@ -40,6 +47,8 @@ struct Stamps {
 #ifdef PNODE_TIMING_BUILD
   unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long prev = 0;
+  unsigned long long when[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // absolute times of the events of this wavefront's (up to two) passes
+  __device__ __forceinline__ void event(int slot) { when[slot] = __builtin_amdgcn_s_memtime(); }
   __device__ __forceinline__ void start() { prev = __builtin_amdgcn_s_memtime(); }
   __device__ __forceinline__ void mark(int slot) {
     const unsigned long long now = __builtin_amdgcn_s_memtime();
@@ -49,6 +58,7 @@ struct Stamps {
 #else
   __device__ __forceinline__ void start() {}
   __device__ __forceinline__ void mark(int) {}
+  __device__ __forceinline__ void event(int) {}
 #endif
 };
 
@@ -65,15 +75,20 @@ __global__ __launch_bounds__(512) void dense_lq4_mfma_kernel(const DenseView v, 
   constexpr int DC = mfma_col_tiles(DT, DD), WC = 16 * DC;
   constexpr int LDV = WC + 1;
   constexpr int DCT = 2 * DD;  // 16-column tiles of the T scratch (columns < 2d)  // odd: the A-operand reads of the G phase (16 rows x 4 column groups) spread over the banks
-  __shared__ double Vx[4 * kNB * LDV];
-  __shared__ double TfS[4 * kNB * kNB];
-  __shared__ double sclS[4 * kNB];
+  // FIVE panel slots for the four panels of a pass: panel j of global pass G has the sequence number n = 4 G + j and lives in
+  // slot n % 5, so a panel may be published while the panel FOUR places before it is still being read -- the first panel of a
+  // pass does not wait for the last trailing update of the pass before to let go of "its" slot (scripts/lq_timeline.py: that
+  // wait was 30-50 k cycles of every trajectory at D = 256).
+  constexpr int NS = 5;
+  __shared__ double Vx[NS * kNB * LDV];
+  __shared__ double TfS[NS * kNB * kNB];
+  __shared__ double sclS[NS * kNB];
   __shared__ double TppS[8 * kNB * kNB];  // diagonal blocks of T, staged by the sweeping wavefront for a coalesced write (one region per
                                           // wavefront: the sweeps of wavefronts j of the two groups overlap across trajectories)
   __shared__ double coefS[2][kMaxN * kMaxN];  // per trajectory, double-buffered by the parity of the workgroup's trajectory count
   __shared__ double pSS[2][kMaxN];
-  __shared__ int pubS[4], storedS[4];
-  __shared__ int doneS[4 * 8];  // doneS[8 k + w] = G: wavefront w will not read the content of slot k of any global pass < G again
+  __shared__ int pubS[NS], storedS[4];  // pubS[s] = n + 1: panel n is in slot s = n % NS
+  __shared__ int nextS[8];  // nextS[w] = n: wavefront w will not read a panel with a sequence number < n again
   __shared__ int prepS;  // number of trajectories whose coefS / pSS are written
   __shared__ int trajS[8];  // trajS[w]: trajectories wavefront w has finished
   __shared__ int abortS;
@@ -86,11 +101,11 @@ __global__ __launch_bounds__(512) void dense_lq4_mfma_kernel(const DenseView v, 
   const int nn = v.n;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int gi = wv >> 2, j = wv & 3;
+  const int gi = wv >> 2, j = wv & 3;  // (wavefront w runs on SIMD w & 3: strip j of both groups on SIMD j)
   if (tid == 0) {
-    for (int k = 0; k < 4; ++k) pubS[k] = storedS[k] = 0;
-    for (int k = 0; k < 32; ++k) doneS[k] = 0;
-    for (int k = 0; k < 8; ++k) trajS[k] = 0;
+    for (int k = 0; k < 4; ++k) storedS[k] = 0;
+    for (int k = 0; k < NS; ++k) pubS[k] = 0;
+    for (int k = 0; k < 8; ++k) trajS[k] = nextS[k] = 0;
     prepS = 0;
     abortS = 0;
   }
@@ -132,19 +147,25 @@ __global__ __launch_bounds__(512) void dense_lq4_mfma_kernel(const DenseView v, 
     asm volatile("" ::: "memory");
   };
   auto lds_done = [] { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
-  // Slot bookkeeping by per-wavefront progress words (not a shared counter: a wavefront may be done with a slot of the running
-  // pass before the slowest one is done with the previous pass, and a counter cannot tell the two apart).
-  auto mark_done = [&](int k, int G) {  // my LDS reads issued so far have completed before the word moves
-    lds_done();
-    if (lane == 0) *(volatile lds_int*)&doneS[8 * k + wv] = G;
+  // Slot bookkeeping by per-wavefront progress words: a wavefront reads the panels in the order of their sequence numbers, except
+  // that the trailing updates of a pass go through its four panels once per block -- its word then moves on the last block only.
+  auto seq = [&](int pass, int k) { return 4 * (base + pass) + k; };
+  auto wait_published = [&](int pass, int k) {
+    const int n = seq(pass, k);
+    spin_ge(&pubS[n % NS], n + 1);
   };
-  auto wait_slot_free = [&](int k, int G) {  // every wavefront is done with slot k of the global passes < G
-    int n = 0;
+  auto done_before = [&](int n) {  // my LDS reads issued so far have completed before the word moves
+    lds_done();
+    if (lane == 0) *(volatile lds_int*)&nextS[wv] = n;
+  };
+  auto done_through = [&](int pass, int k) { done_before(seq(pass, k) + 1); };
+  auto wait_slot_free = [&](int n) {  // every wavefront is done with the panel this slot held before panel n
+    int polls = 0;
     while (true) {
-      const int mine = (lane < 8) ? *(volatile lds_int*)&doneS[8 * k + lane] : 0x7fffffff;
-      if (!__any(mine < G)) break;
+      const int mine = (lane < 8) ? *(volatile lds_int*)&nextS[lane] : 0x7fffffff;
+      if (!__any(mine < n - NS + 1)) break;
       __builtin_amdgcn_s_sleep(2);
-      if (((++n & 255) == 0 || n > spin_limit) && timed_out(n, 1, G)) break;
+      if (((++polls & 255) == 0 || polls > spin_limit) && timed_out(polls, 1, n)) break;
     }
     asm volatile("" ::: "memory");
   };
@@ -216,12 +237,13 @@ __global__ __launch_bounds__(512) void dense_lq4_mfma_kernel(const DenseView v, 
   // panel k of pass `pass` applied to my strip (global strip index st_), once it is published. (Raising the issue priority of
   // the applications the chain is waiting for changed nothing measurable.)
   auto apply_panel = [&](int pass, int k, int st_) {
-    spin_ge(&pubS[k], base + pass + 1);
+    const int sl = seq(pass, k) % NS;
+    spin_ge(&pubS[sl], seq(pass, k) + 1);
     st.mark(1);
     const int r = opaque(lane & 15), g = opaque(lane >> 4);
     const int j0 = kNB * st_, cp = 64 * pass + kNB * k;
     double4_t tv;
-    apply_panel_to_strip_pipelined<DC, LDV>(X, Vx + k * kNB * LDV, TfS + k * kNB * kNB, sclS + k * kNB, t0_tile(j0, cp, r, g), tv, r, g);
+    apply_panel_to_strip_pipelined<DC, LDV>(X, Vx + sl * kNB * LDV, TfS + sl * kNB * kNB, sclS + sl * kNB, t0_tile(j0, cp, r, g), tv, r, g);
     const bool direct = is_direct(pass);
     if (direct) {  // strip order of the state factor (column c of L^- is column c - d of Ls): two pairs per lane, 16 lanes of a pair contiguous
       tv = transpose_groups(tv);  // lane (r, g): columns cp + 4 g .. cp + 4 g + 3 of row j0 + r
@@ -314,25 +336,30 @@ __global__ __launch_bounds__(512) void dense_lq4_mfma_kernel(const DenseView v, 
         // panel j is out. (No cycle: its publication waits for marks I set before I entered this phase. Measured: 662 k -> 594 k
         // cycles per trajectory. s_setprio does not arbitrate the matrix core; a flag raised and polled around the critical
         // application only moved the collision into the sweep.)
-        if (k == j - 1) spin_ge(&pubS[j], base + 1);
+        if (k == j - 1) wait_published(0, j);
         apply_panel(0, k, 4 + j);
-        mark_done(k, base + 1);
+        done_through(0, k);
       }
     }
 #pragma unroll 1
     for (int P = gi; P < NBLK; P += 2) {
       const bool has_trailing = P + 2 < NBLK;
       const int mystrip = 4 * P + j;
+      // The first pass of a trajectory (group A) runs beside the last pass of the one before when that is group B's, and the slot
+      // hand-over ties panel j of the one to panel j of the other: the two wavefronts j share SIMD j, and two sweeps side by side
+      // on one SIMD take 31 k cycles instead of 15 k each (scripts/lq_timeline.py: 44 k per panel of both passes). So the chain of
+      // the first pass FOLLOWS the other by one panel: its work on SIMD j -- the application of panel j - 1 to strip j, sweep j --
+      // starts when the other chain has left that SIMD (its panel j is out).
+      const bool follows = P == 0 && it > 0 && ((NBLK - 1) & 1) == 1;
       // ================= chain of pass P: the panels before mine, then my strip becomes panel j
       // (unrolled with guards: as a loop with a run-time trip count, with the strip live into and out of it, the register allocator
       // parks the strip in scratch)
 #pragma unroll
       for (int kk = 0; kk < 3; ++kk) {
         if (kk < j) {
+          if (kk == j - 1 && follows) wait_published(-1, j);
           apply_panel(P, kk, mystrip);
-          // (no further role in this trajectory after a pass without trailing blocks: sign off for ALL its remaining passes, so
-          // that wavefront 0 of this group may publish into the slot for the NEXT trajectory as soon as the other group is done)
-          if (!has_trailing) mark_done(kk, base + NBLK);
+          if (!has_trailing) done_through(P, kk);  // (with trailing blocks the panels of the pass are read again)
         }
       }
       {
@@ -343,24 +370,33 @@ __global__ __launch_bounds__(512) void dense_lq4_mfma_kernel(const DenseView v, 
 #pragma unroll
         for (int m = 0; m < kNB; ++m) tfrow[m] = 0.0;
         double* tpp_row = TppS + wv * kNB * kNB + r * kNB;
+        if (j == 0 && follows) {
+          wait_published(-1, 0);
+          st.mark(1);
+        }
+        st.event(4 * (P >> 1));  // arrived at the sweep
         __builtin_amdgcn_s_setprio(3);
         pivot_sweep<0, DC>(X, tfrow, tpp_row, myscl, alpha);
         __builtin_amdgcn_s_setprio(0);
         st.mark(3);
-        wait_slot_free(j, base + P);  // every wavefront is done with this slot's panels of the passes before
+        st.event(4 * (P >> 1) + 1);  // swept
+        const int myseq = seq(P, j), sl = myseq % NS;
+        wait_slot_free(myseq);  // every wavefront is done with the panel the slot held before
         st.mark(4);
-        double* Vp = Vx + j * kNB * LDV;
+        st.event(4 * (P >> 1) + 2);  // slot free
+        double* Vp = Vx + sl * kNB * LDV;
 #pragma unroll
         for (int T4 = 0; T4 < DC / 4; ++T4)
 #pragma unroll
           for (int e = 0; e < 16; ++e) Vp[r * LDV + 64 * T4 + 16 * g + e] = X[16 * T4 + e];
         if (g == 0) {
-          sclS[j * kNB + r] = myscl;
+          sclS[sl * kNB + r] = myscl;
 #pragma unroll
-          for (int m = 0; m < kNB; ++m) TfS[j * kNB * kNB + r * kNB + m] = tfrow[m];
+          for (int m = 0; m < kNB; ++m) TfS[sl * kNB * kNB + r * kNB + m] = tfrow[m];
         }
         lds_done();
-        if (lane == 0) *(volatile lds_int*)&pubS[j] = base + P + 1;
+        if (lane == 0) *(volatile lds_int*)&pubS[sl] = myseq + 1;
+        st.event(4 * (P >> 1) + 3);  // published
         {
           // diagonal block of T (zeros above the diagonal; the sweep leaves the upper triangle of tpp unwritten)
           const int row = cp + r;
@@ -382,10 +418,8 @@ __global__ __launch_bounds__(512) void dense_lq4_mfma_kernel(const DenseView v, 
         }
         st.mark(5);
       }
-      if (!has_trailing) {
-#pragma unroll 1
-        for (int k = j; k < 4; ++k) mark_done(k, base + NBLK);  // (slots I do not read in this pass, nor later in this trajectory)
-      }
+      // (no further role in this trajectory after a pass without trailing blocks: the next panel I read is one of the next trajectory)
+      if (!has_trailing) done_before(seq(NBLK, 0));
       // ================= the other blocks of pass P: strip j of the blocks P + 3 .. goes back to HBM, strip j of block P + 2 stays
 #pragma unroll 1
       for (int blk = NBLK - 1; blk >= P + 2; --blk) {
@@ -398,7 +432,7 @@ __global__ __launch_bounds__(512) void dense_lq4_mfma_kernel(const DenseView v, 
 #pragma unroll 1
         for (int k = 0; k < 4; ++k) {
           apply_panel(P, k, 4 * blk + j);
-          if (blk == P + 2) mark_done(k, base + P + 1);
+          if (blk == P + 2) done_through(P, k);
         }
         if (blk != P + 2) store_strip(4 * blk + j);
         st.mark(6);
@@ -411,17 +445,14 @@ __global__ __launch_bounds__(512) void dense_lq4_mfma_kernel(const DenseView v, 
       if (has_trailing) {
 #pragma unroll 1
         for (int k = 0; k < 4; ++k) {
-          if (k == j - 1) spin_ge(&pubS[j], base + P + 2);  // (stay off the SIMD while its other wavefront is the chain's, see the prologue)
+          if (k == j - 1) wait_published(P + 1, j);  // (stay off the SIMD while its other wavefront is the chain's, see the prologue)
           apply_panel(P + 1, k, 4 * (P + 2) + j);
-          mark_done(k, base + P + 2);
+          done_through(P + 1, k);
         }
       }
     }
     // the group that has no role in the last pass (its panels are applied inside the panel group only) signs off for it
-    if (gi == (NBLK & 1)) {
-#pragma unroll 1
-      for (int k = 0; k < 4; ++k) mark_done(k, base + NBLK);
-    }
+    if (gi == (NBLK & 1)) done_before(seq(NBLK, 0));
     ++it;
     lds_done();
     if (lane == 0) *(volatile lds_int*)&trajS[wv] = it;
@@ -429,6 +460,7 @@ __global__ __launch_bounds__(512) void dense_lq4_mfma_kernel(const DenseView v, 
     if (lane == 0) {
       unsigned long long* dbg = reinterpret_cast<unsigned long long*>(v.S + size_t(b) * d * d) + wv * 8;
       for (int i = 0; i < 8; ++i) dbg[i] = st.acc[i];
+      for (int i = 0; i < 8; ++i) dbg[64 + i] = st.when[i];
     }
 #endif
     if (*abort_word) {
