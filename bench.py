@@ -216,6 +216,12 @@ def extras(args, batch, loop, active, dense, device_ctl, device):
             r["algorithmic_bytes_per_step"] = byts
             r["hbm_GBps"] = r["attempted"] / r["seconds"] * byts / 1e9
             r["hbm_frac"] = r["hbm_GBps"] / HBM_PEAK_GBS
+            if dev:
+                # the device-resident controller keeps the state of a trajectory in the registers of its wavefront over the attempts of
+                # a launch and writes only accepted states: the bytes it actually moves are half of SURVEY's figure, and the loop
+                # is bound by the latency of one attempt (a serial chain per trajectory), not by HBM
+                r["moved_bytes_per_accepted_step"] = byts // 2
+                r["us_per_attempt_of_a_trajectory"] = r["seconds"] / (r["attempted"] / B) * 1e6
             iso[name] = r
         out["isotropic_ekf0_nu3"] = {"workload": f"Brusselator N=32 (d=64), nu=3, isotropic EKF0 (the reference's own model for this PDE), "
                                                  f"filter, dynamic, tol 1e-6, batch {B}, whole solve t in [0, 10]", **iso}

@@ -219,6 +219,132 @@ __device__ __forceinline__ double team_sum(double v, double* red, int wteam) {
   return t;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Filter, d <= 64, one wavefront per trajectory: ONE column of the mean per lane, and the state of a trajectory fits the registers
+// of its wavefront -- the attempted step as a function from registers to registers. iso_attempt (one launch per attempt, host
+// controller) wraps it in a load and a store; the device-resident controller (iso_advance_kernel) keeps the last accepted
+// state in registers over all the attempts of a launch and writes a state to its slot only when it is accepted: an attempt
+// then waits for no global memory at all (before: six dependent round trips per attempt, 33 k of its 45 k cycles at d = 64,
+// nu = 3). Same arithmetic, expression by expression, as the general path below. (The fixed-point smoother stays on the general
+// path: with the running backward transition beside two states the registers spill, and its attempt is bound by the three
+// Givens sweeps every lane computes, not by the round trips -- measured: no gain at nu = 3, 4, a loss of 6-9 % at nu = 5.)
+// ---------------------------------------------------------------------------------------------
+template <int N>
+struct IsoRegs {
+  double m[N];     // my column of the mean (lanes < d)
+  double R[N][N];  // factor, wave-uniform
+  double sigma;
+};
+
+template <int N>
+__device__ __forceinline__ void iso_load_regs(const IsoView& v, int b, int lane, int slot, IsoRegs<N>& s) {
+  const int d = v.d;
+  const size_t sB = size_t(v.B);
+  const double* msrc = v.mean + (size_t(slot) * sB + b) * N * d;
+#pragma unroll
+  for (int i = 0; i < N; ++i) s.m[i] = lane < d ? msrc[i * d + lane] : 0.0;
+  load_small<N>(v.fac + (size_t(slot) * sB + b) * N * N, s.R);
+  s.sigma = v.sigma[size_t(slot) * sB + b];
+}
+
+template <int N>
+__device__ __forceinline__ void iso_store_regs(const IsoView& v, int b, int lane, int slot, const IsoRegs<N>& o) {
+  const int d = v.d;
+  const size_t sB = size_t(v.B);
+  double* mdst = v.mean + (size_t(slot) * sB + b) * N * d;
+  if (lane < d) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) mdst[i * d + lane] = o.m[i];
+  }
+  store_small<N>(v.fac + (size_t(slot) * sB + b) * N * N, o.R, lane);
+  if (lane == 0) v.sigma[size_t(slot) * sB + b] = o.sigma;
+}
+
+// One attempted step from the state `s`. Returns the normalised error norm.
+template <int N>
+__device__ __forceinline__ double iso_attempt_regs(const IsoView& v, const IwpConst& K, int b, int lane, double dt, double t,
+                                                   const IsoRegs<N>& s, IsoRegs<N>& o, double atol, double rtol, double* ybuf) {
+  const int d = v.d, k = v.k;
+  const bool on = lane < d;
+  double p[N], pinv[N];
+  preconditioner<N>(dt, K, p, pinv);
+
+  // --- mean extrapolation  m^- = P Abar P^{-1} m
+  double me[N];
+  {
+    double mp[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) mp[i] = pinv[i] * s.m[i];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      double acc = 0.0;
+#pragma unroll
+      for (int kk = i; kk < N; ++kk) acc += K.a[i][kk] * mp[kk];
+      const double e = p[i] * acc;
+      me[i] = e;
+      if (on && i < k) ybuf[i * d + lane] = e;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0);  // LDS writes of this wave visible to all its lanes
+
+  // --- residual z = m^-[k] - f(m^-[<k])  and its norm
+  VfCtx ctx{v.vf_id, d, k, v.prm ? v.prm + (v.prm_per_traj ? size_t(b) * v.P : 0) : nullptr,
+            v.user_f ? v.user_f + size_t(b) * d : nullptr, v.user_J ? v.user_J + size_t(b) * d * k * d : nullptr};
+  const double tnew = t + dt;
+  double z = 0.0, zz = 0.0;
+  if (on) {
+    z = me[k] - vf_f(ctx, ybuf, lane, tnew);
+    zz += z * z;
+  }
+  zz = wave_sum(zz);
+  __builtin_amdgcn_wave_barrier();  // (ybuf is rewritten by the next attempt)
+
+  // --- calibration + error estimate
+  const double s1 = p[k] * K.qdiag_sqrt[k];
+  const double sigma_hat = sqrt(zz) / (s1 * sqrt(double(d)));
+  const double err = dt * sigma_hat * s1;
+  const double sigma = v.dynamic ? sigma_hat : s.sigma;
+
+  // --- n x n square-root time update
+  double Rm[N][N], Gunused[N][N], RLunused[N][N];
+  iso_time_update<N, false>(K, s.R, p, pinv, sigma, Rm, Gunused, RLunused);
+
+  // --- correction on z = 0
+  double F[N], gain[N];
+  double s2 = 0.0;
+#pragma unroll
+  for (int c = 0; c < N; ++c) {
+    F[c] = Rm[c][k];
+    s2 += F[c] * F[c];
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    double acc = 0.0;
+#pragma unroll
+    for (int c = 0; c < N; ++c) acc += Rm[c][i] * F[c];
+    gain[i] = acc / s2;
+  }
+#pragma unroll
+  for (int c = 0; c < N; ++c)
+#pragma unroll
+    for (int i = 0; i < N; ++i) o.R[c][i] = Rm[c][i] - F[c] * gain[i];
+
+  // --- corrected mean + normalised error norm
+  double acc2 = 0.0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) o.m[i] = me[i] - gain[i] * z;
+  if (on) {
+    const double rel = err / (atol + rtol * fabs(o.m[0]));
+    acc2 += rel * rel;
+  }
+  acc2 = wave_sum(acc2);
+  o.sigma = sigma;
+  return sqrt(acc2 / double(d));
+}
+
 // One attempted step of trajectory b by a team of W wavefronts (W = 1: one wave per trajectory, four
 // trajectories per workgroup; W = 4: the whole 256-thread workgroup works on one trajectory, used for large d):
 // reads slot arg.src, writes slot arg.dst, returns the normalised error norm (team-uniform). `lane` is the
@@ -230,6 +356,15 @@ __device__ __forceinline__ double iso_attempt(const IsoView& v, const IwpConst& 
   constexpr int kTeam = kWave * W;
   const int wteam = lane >> 6;
   const int d = v.d, k = v.k;
+  if constexpr (W == 1 && !FP) {
+    if (d <= kWave) {  // one column per lane: the register form above
+      IsoRegs<N> s, o;
+      iso_load_regs<N>(v, b, lane, arg.src, s);
+      const double e = iso_attempt_regs<N>(v, K, b, lane, arg.dt, arg.t, s, o, v.atol[b], v.rtol[b], ybuf);
+      iso_store_regs<N>(v, b, lane, arg.dst, o);
+      return e;
+    }
+  }
 
   const double dt = arg.dt;
   double p[N], pinv[N];
@@ -380,6 +515,36 @@ __global__ __launch_bounds__(256) void iso_step_kernel(IsoView v, const StepArg*
 // step-size law for ITS trajectory until the next save_at point is reached (or an iteration budget is spent), so
 // the host synchronises once per checkpoint interval instead of once per attempted step. Same arithmetic as the
 // host controller in pnode_solve_adaptive_save_at.
+// The controller's bookkeeping after an attempt with error norm e and step dt (both loops of iso_advance_kernel): returns
+// whether the state of the attempt is accepted; c.status = 2 ends the loop.
+__device__ __forceinline__ bool iso_after_attempt(TrajCtl& c, const ControlParams& cp, double e, double dt) {
+  c.attempts += 1;
+  bool accept;
+  if (e != e) {
+    c.status = 2;  // NaN error estimate: stop (the reference accepts the NaN state and fails later)
+    accept = true;
+  } else {
+    const double le = log(e);
+    const double raw = cp.safety * exp(cp.n2 * c.log_prev - (cp.n1 + cp.n2) * le);
+    const double factor = fmax(cp.factor_min, fmin(raw, cp.factor_max));
+    if (e <= 1.0) c.log_prev = le;
+    c.dt = factor * dt;
+    accept = !(e > 1.0);
+  }
+  if (accept) {
+    c.s_if = c.s_sf;
+    c.t_if = c.t_sf;
+    c.s_sf = c.s_pr;
+    c.t_sf += dt;
+    c.steps += 1;
+    int fr = 0;
+    while (fr == c.s_if || fr == c.s_sf) ++fr;
+    c.s_pr = fr;
+  }
+  if (c.status != 2 && !(isfinite(c.dt) && isfinite(c.t_sf) && c.dt > 0.0)) c.status = 2;
+  return accept;
+}
+
 template <int N, bool FP, int W>
 __global__ __launch_bounds__(256) void iso_advance_kernel(IsoView v, TrajCtl* __restrict__ ctl, const IwpConst* __restrict__ Kc,
                                                           ControlParams cp) {
@@ -396,42 +561,42 @@ __global__ __launch_bounds__(256) void iso_advance_kernel(IsoView v, TrajCtl* __
   double* red = zbuf + v.d;
   int iters = 0;
   c.status = 0;
-  while (c.t_sf + cp.numerical_zero < c.t_stop && iters < cp.max_iters) {
-    double dt = c.dt;
-    if (cp.clip) dt = fmin(dt, c.t_stop - c.t_sf);
-    StepArg arg;
-    arg.dt = dt; arg.t = c.t_sf; arg.src = c.s_sf; arg.dst = c.s_pr; arg.active = 1; arg.pad = 0;
-    const double e = iso_attempt<N, FP, W>(v, *Kc, b, lane, arg, ybuf, zbuf, red);
-    if constexpr (W > 1) __syncthreads();
-    __threadfence_block();  // the slot written by this attempt is read by the next one (other lanes of the team)
-    ++iters;
-    c.attempts += 1;
-    bool accept;
-    if (e != e) {
-      c.status = 2;  // NaN error estimate: stop (the reference accepts the NaN state and fails later)
-      accept = true;
-    } else {
-      const double le = log(e);
-      const double raw = cp.safety * exp(cp.n2 * c.log_prev - (cp.n1 + cp.n2) * le);
-      const double factor = fmax(cp.factor_min, fmin(raw, cp.factor_max));
-      if (e <= 1.0) c.log_prev = le;
-      c.dt = factor * dt;
-      accept = !(e > 1.0);
+  bool in_registers = false;
+  if constexpr (W == 1 && !FP) in_registers = v.d <= kWave;
+  if (in_registers) {
+    if constexpr (W == 1 && !FP) {
+      // the last accepted state stays in registers; a state goes to its slot when it is accepted (the slots STEP_FROM and
+      // INTERP_FROM are what the host reads after the launch), a rejected attempt leaves no trace
+      const IwpConst& K = *Kc;
+      const double atol = v.atol[b], rtol = v.rtol[b];
+      IsoRegs<N> cur;
+      iso_load_regs<N>(v, b, lane, c.s_sf, cur);
+      while (c.t_sf + cp.numerical_zero < c.t_stop && iters < cp.max_iters) {
+        double dt = c.dt;
+        if (cp.clip) dt = fmin(dt, c.t_stop - c.t_sf);
+        IsoRegs<N> nw;
+        const double e = iso_attempt_regs<N>(v, K, b, lane, dt, c.t_sf, cur, nw, atol, rtol, ybuf);
+        ++iters;
+        const int dst = c.s_pr;
+        if (iso_after_attempt(c, cp, e, dt)) {
+          iso_store_regs<N>(v, b, lane, dst, nw);
+          cur = nw;
+        }
+        if (c.status == 2) break;
+      }
     }
-    if (accept) {
-      c.s_if = c.s_sf;
-      c.t_if = c.t_sf;
-      c.s_sf = c.s_pr;
-      c.t_sf += dt;
-      c.steps += 1;
-      int fr = 0;
-      while (fr == c.s_if || fr == c.s_sf) ++fr;
-      c.s_pr = fr;
-    }
-    if (c.status == 2) break;
-    if (!(isfinite(c.dt) && isfinite(c.t_sf) && c.dt > 0.0)) {
-      c.status = 2;
-      break;
+  } else {
+    while (c.t_sf + cp.numerical_zero < c.t_stop && iters < cp.max_iters) {
+      double dt = c.dt;
+      if (cp.clip) dt = fmin(dt, c.t_stop - c.t_sf);
+      StepArg arg;
+      arg.dt = dt; arg.t = c.t_sf; arg.src = c.s_sf; arg.dst = c.s_pr; arg.active = 1; arg.pad = 0;
+      const double e = iso_attempt<N, FP, W>(v, *Kc, b, lane, arg, ybuf, zbuf, red);
+      if constexpr (W > 1) __syncthreads();
+      __threadfence_block();  // the slot written by this attempt is read by the next one (other lanes of the team)
+      ++iters;
+      iso_after_attempt(c, cp, e, dt);
+      if (c.status == 2) break;
     }
   }
   if (c.status == 0) c.status = (c.t_sf + cp.numerical_zero >= c.t_stop) ? 1 : 3;
