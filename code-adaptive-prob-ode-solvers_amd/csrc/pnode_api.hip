@@ -120,6 +120,15 @@ __global__ void dense_ctl_kernel(TrajCtl* __restrict__ ctl, StepArg* __restrict_
   ctl[b] = c;
 }
 
+// Dense fixed-point smoother under the device-resident controller: the backward-transition kernels that follow the step take
+// their arguments (FpArg) from the StepArg the controller kernel has just written.
+__global__ void fp_args_from_step_args_kernel(const StepArg* __restrict__ args, FpArg* __restrict__ fp, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const StepArg a = args[b];
+  fp[b] = FpArg{a.dt, a.src, a.dst, 1, a.active, 0, 0};
+}
+
 }  // namespace
 
 struct pnode_batch {
@@ -138,6 +147,7 @@ struct pnode_batch {
   DenseView dn{};
   IwpConst* dK = nullptr;
   TrajCtl* dCtl = nullptr;      // device-resident controller state (multi-kernel form)
+  FpArg* dFp = nullptr;         // arguments of the backward-transition kernels in that form (dense fixed-point smoother)
   StepArg* dArgs = nullptr;
   InterpArg* dIargs = nullptr;
   int32_t* dFilled = nullptr;
@@ -282,6 +292,7 @@ int pnode_create(const pnode_config* cfg, pnode_batch** out) {
   ALLOC(h->dK, 1);
   ALLOC(h->dArgs, B);
   ALLOC(h->dCtl, B);
+  ALLOC(h->dFp, B);
   ALLOC(h->dIargs, B);
   ALLOC(h->dFilled, B);
   ALLOC(h->dAtol, B);
@@ -515,6 +526,10 @@ static int advance_rounds_device(pnode_batch* h, TrajCtl* hCtl, const ControlPar
       enqueue_step(h, h->dArgs, h->dErr, per_round ? &h->phase_pool[size_t(r)] : nullptr, &fc);
     } else {
       enqueue_step(h, h->dArgs, h->dErr, per_round ? &h->phase_pool[size_t(r)] : nullptr);
+      if (h->dense && h->dn.fixedpoint) {  // backward transition of the attempt, merged with the running one (as pnode_attempt_step)
+        hipLaunchKernelGGL(fp_args_from_step_args_kernel, dim3(blocks), dim3(256), 0, h->stream, h->dArgs, h->dFp, int(B));
+        dense_fp_launch_step_tail(h->dn, h->dFp, h->dK, h->stream);
+      }
       hipLaunchKernelGGL(dense_ctl_kernel, dim3(blocks), dim3(256), 0, h->stream, h->dCtl, h->dArgs, h->dErr, cp, int(B), 0);
     }
   }
@@ -811,8 +826,6 @@ int pnode_solve_adaptive_save_at_device(pnode_batch* h, const double* save_at, i
   if (!h->initialised) return fail(PNODE_ESTATE, "set_initial has not been called");
   // dense model beyond the fused one-wavefront kernel: multi-kernel form (controller kernel between the attempts), filter only
   const bool multi = h->dense && !(dense_small_supported(h->dn) && !h->dn.force_generic);
-  if (multi && h->dn.fixedpoint)
-    return fail(PNODE_EINVAL, "the device-resident controller of the dense model is implemented for strategy_filter");
   if (h->cfg.vf_id == PNODE_VF_USER) return fail(PNODE_EINVAL, "the device-resident controller needs a built-in vector field");
   HIP_TRY(hipSetDevice(h->cfg.device));
   const size_t B = h->cfg.batch;
@@ -944,7 +957,6 @@ int pnode_advance_device(pnode_batch* h, const double* t_stop, double* dt_inout,
   if (!h || !t_stop || !dt_inout || !log_err_prev_inout || !ctrl || !status_out || !attempts_out || rounds < 1)
     return fail(PNODE_EINVAL, "bad argument");
   if (!h->initialised) return fail(PNODE_ESTATE, "set_initial has not been called");
-  if (h->dense && h->dn.fixedpoint) return fail(PNODE_EINVAL, "pnode_advance_device: strategy_filter only for the dense model");
   if (h->cfg.vf_id == PNODE_VF_USER) return fail(PNODE_EINVAL, "the device-resident controller needs a built-in vector field");
   HIP_TRY(hipSetDevice(h->cfg.device));
   const size_t B = h->cfg.batch;

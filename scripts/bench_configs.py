@@ -91,6 +91,16 @@ def main():
                 atol=1e-6, rtol=1e-6, dt0=0.01, device_controller=dev)
         config5()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "c4fp":
+        # the headline shape with fixed-memory checkpoint smoothing (dense fixed-point smoother, D = 256: extra-row LQ and
+        # backward-transition merge on the large-D kernels), both controllers
+        import bench
+
+        vf, tcs = bench.problem_batch(1024)
+        for dev in (False, True):
+            run("C4 brusselator dense EKF1 nu=3 fixedpoint, 5 save_at points", vf, [tcs[0]], 0.0, 10.0, model="dense", corr="ts1",
+                strategy="fixedpoint", nu=3, atol=1e-6, rtol=1e-6, dt0=0.01, device_controller=dev)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "c5full":
         D, K, B = 1024, 199, 64
         plan = {"per_trajectory_MB": {"checkpoint transitions ck_G + ck_Lam (K x 2 x D^2 x 8 B)": 2 * K * D * D * 8 / 2**20,
