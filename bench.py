@@ -211,7 +211,10 @@ def extras(args, batch, loop, active, dense, device_ctl, device):
         iso = {}
         for name, dev in (("device_controller", True), ("host_controller", False)):
             whole_solve("isotropic", B, dev, device)  # warm-up (code paging)
-            r = whole_solve("isotropic", B, dev, device)
+            # fastest of three: the timed region includes the creation of the handle (device and pinned-host allocations, tens of
+            # milliseconds on some boxes) and the read-back, which a 25 ms solve does not hide
+            r = min((whole_solve("isotropic", B, dev, device) for _ in range(3)), key=lambda x: x["seconds"])
+            r["timing"] = "fastest of 3 whole solves, handle creation and read-back included"
             byts = 2 * 8 * (n * d + n * n)  # state in + out per attempted step
             r["algorithmic_bytes_per_step"] = byts
             r["hbm_GBps"] = r["attempted"] / r["seconds"] * byts / 1e9

@@ -243,7 +243,7 @@ void* pnode_stream(pnode_batch* h);
  * status_out[b]: in < 0 = trajectory does not take part; out 0 = still short of t_stop[b], 1 = STEP_FROM.t + nz >= t_stop[b],
  * 2 = failed (non-finite). dt_inout / log_err_prev_inout carry the controller state (log of the previous accepted error norm,
  * 0 initially); attempts_out[b] = attempts made in this call. pnode_solve_adaptive_save_at_device uses it for the dense model
- * beyond (nu+1) d = 32 (strategy_filter); bench.py uses it for the timed region of the headline. */
+ * beyond (nu+1) d = 32 (strategy_filter and strategy_fixedpoint); bench.py uses it for the timed region of the headline. */
 int pnode_advance_device(pnode_batch* h, const double* t_stop, double* dt_inout, double* log_err_prev_inout, const pnode_control* ctrl,
                          double numerical_zero, int32_t rounds, int32_t* status_out, int64_t* attempts_out);
 
