@@ -678,6 +678,16 @@ __device__ __forceinline__ void apply_all_panels(double (&X)[4 * DF], const doub
 // trajectory (controller_decision, pnode_common.hpp): no controller kernel between the attempts. (Running the first phase of the
 // NEXT attempt here as well -- two launches per attempt -- was measured and dropped: its serial Cholesky at two workgroups per CU
 // costs more than the begin kernel at four, 0.340 against 0.261 + 0.049 ms at B = 1024.)
+// Cycle stamps of the diagnostic build (make timing; scripts/correct_phase_stamps.py); empty otherwise.
+struct CorrectStamps {
+#ifdef PNODE_TIMING_BUILD
+  unsigned long long t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  __device__ __forceinline__ void at(int i) { t[i] = __builtin_amdgcn_s_memtime(); }
+#else
+  __device__ __forceinline__ void at(int) {}
+#endif
+};
+
 template <int DT, int DD, bool CTL>
 __global__ __launch_bounds__(256, 2) void dense_correct_mfma_kernel(DenseView v, StepArg* __restrict__ args, const IwpConst* __restrict__ Kc,
                                                                     TrajCtl* __restrict__ ctl, ControlParams cp) {
@@ -712,6 +722,8 @@ __global__ __launch_bounds__(256, 2) void dense_correct_mfma_kernel(DenseView v,
     }
     return;
   }
+  CorrectStamps cs;
+  cs.at(0);
   double p[kMaxN], pinv[kMaxN];
   precond_rt(v.n, arg.dt, K, p, pinv);
   const double p0 = p[0], p1 = p[1];
@@ -760,6 +772,7 @@ __global__ __launch_bounds__(256, 2) void dense_correct_mfma_kernel(DenseView v,
     }
   }
   __syncthreads();  // wz
+  cs.at(1);
   // ---- blocked row-Householder LQ of F: wavefront w sweeps strip w in registers (pnode_lq_sweep.hpp); its panel stays in LDS
 #pragma unroll 1
   for (int pnl = 0; pnl < DD; ++pnl) {
@@ -806,6 +819,7 @@ __global__ __launch_bounds__(256, 2) void dense_correct_mfma_kernel(DenseView v,
     }
   }
   __syncthreads();
+  cs.at(2);
   // ---- the panels from the plain column order to the order of the strips, in place: slot 16 g + e of a super-tile (plain:
   //      column 16 g + e) moves to slot 16 (e & 3) + 4 g + (e >> 2) (there, register e' = 4 a + q of group g' is column
   //      16 a + 4 q + g'); every thread takes half a super-tile of one row
@@ -833,6 +847,7 @@ __global__ __launch_bounds__(256, 2) void dense_correct_mfma_kernel(DenseView v,
     }
   }
   __syncthreads();
+  cs.at(3);
   // ---- every 16-row strip of L^- = diag(p) T (first 2d columns) rotated by the panels: X Q = [Y1 | Y2]. Y1 = L^- W^T feeds the
   //      mean, Y2 = L^- Q2 becomes the dense part of the new rank-(D - d) state factor (its columns 0 .. d-1, in the order the
   //      registers hold them: the column order of a factor is immaterial); the columns >= 2d of L^- were written by the LQ kernel
@@ -878,7 +893,9 @@ __global__ __launch_bounds__(256, 2) void dense_correct_mfma_kernel(DenseView v,
   }
   {
     // error norm over u = m[0] (rows 0 .. d-1 were updated above)
+    cs.at(4);
     __syncthreads();
+    cs.at(5);
     const double atol = v.atol[b], rtol = v.rtol[b];
     double part = 0.0;
     for (int j = tid; j < d; j += 256) {
@@ -902,6 +919,13 @@ __global__ __launch_bounds__(256, 2) void dense_correct_mfma_kernel(DenseView v,
         ctl[b] = c;
       }
     }
+    cs.at(6);
+#ifdef PNODE_TIMING_BUILD
+    if (lane == 0) {  // (behind the 128 words of the LQ kernel's stamps)
+      unsigned long long* dbg = reinterpret_cast<unsigned long long*>(v.S + size_t(b) * d * d) + 128 + wv * 8;
+      for (int i = 0; i < 7; ++i) dbg[i] = cs.t[i];
+    }
+#endif
   }
 }
 
