@@ -47,86 +47,74 @@ __device__ __forceinline__ void iso_time_update(const IwpConst& K, const double 
   for (int c = 0; c < N; ++c)
 #pragma unroll
     for (int i = 0; i < N; ++i) R[c][i] = (i >= c) ? sigma * K.qsT[c][i] : 0.0;
+  if constexpr (!COND) {
 #pragma unroll
-  for (int c = 0; c < N; ++c) {
-    double x[N];
+    for (int c = 0; c < N; ++c) {
+      double x[N];
 #pragma unroll
-    for (int i = 0; i < N; ++i) x[i] = M[c][i];
-    givens_rotate_in<N>(R, x);
-  }
-  if constexpr (COND) {
-    // cross = Sigma~ Abar^T = Bm^T M ;  Gp = cross (R^T R)^{-1}
-    double Gp[N][N];
-    double rinv[N];
-#pragma unroll
-    for (int j = 0; j < N; ++j) rinv[j] = (R[j][j] != 0.0) ? fast_rcp(R[j][j]) : 0.0;
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-      double row[N];
-#pragma unroll
-      for (int j = 0; j < N; ++j) {
-        double acc = 0.0;
-#pragma unroll
-        for (int c = 0; c < N; ++c) acc += Bm[c][i] * M[c][j];
-        row[j] = acc;
-      }
-      // y R = row  (R upper: forward over columns); rinv: reciprocal pivots, 0 on an exactly singular factor
-#pragma unroll
-      for (int j = 0; j < N; ++j) {
-        double acc = row[j];
-#pragma unroll
-        for (int k = 0; k < j; ++k) acc -= row[k] * R[k][j];
-        row[j] = acc * rinv[j];
-      }
-      // x R^T = y  (backward)
-#pragma unroll
-      for (int j = N - 1; j >= 0; --j) {
-        double acc = row[j];
-#pragma unroll
-        for (int k = j + 1; k < N; ++k) acc -= row[k] * R[j][k];
-        row[j] = acc * rinv[j];
-      }
-#pragma unroll
-      for (int j = 0; j < N; ++j) Gp[i][j] = row[j];
+      for (int i = 0; i < N; ++i) x[i] = M[c][i];
+      givens_rotate_in<N>(R, x);
     }
-    // Lambda (Joseph form, square-root): rows of Bm (I - Gp Abar)^T and sigma*qsT*Gp^T
-    double T[N][N];
-#pragma unroll
-    for (int i = 0; i < N; ++i)
-#pragma unroll
-      for (int k = 0; k < N; ++k) {
-        double acc = (i == k) ? 1.0 : 0.0;
-#pragma unroll
-        for (int j = 0; j <= k; ++j) acc -= Gp[i][j] * K.a[j][k];
-        T[i][k] = acc;
-      }
+  } else {
+    // ONE triangularisation of the stack [sigma chol(Qbar)^T 0 ; M Bm] (2n x 2n) = Q [R R12 ; 0 R22], as the reference's
+    // revert_conditional does it: R^T R = Sigma^-, R^T R12 = cov(x_new, x_prev), R22^T R22 = the backward noise Lambda (Schur
+    // complement), gain Gp = (R^-1 R12)^T. The rotations that build R are the ones of the filter (same order, same
+    // arithmetic: R comes out bit for bit as without COND); the columns of R12 ride along, and what is left of a row goes into R22.
+    double R12[N][N], R22[N][N];
 #pragma unroll
     for (int c = 0; c < N; ++c)
 #pragma unroll
-      for (int i = 0; i < N; ++i) RL[c][i] = 0.0;
+      for (int i = 0; i < N; ++i) R12[c][i] = R22[c][i] = 0.0;
 #pragma unroll
     for (int c = 0; c < N; ++c) {
-      double x[N];
+      double x[N], y[N];
 #pragma unroll
       for (int i = 0; i < N; ++i) {
-        double acc = 0.0;
-#pragma unroll
-        for (int k = 0; k < N; ++k) acc += Bm[c][k] * T[i][k];
-        x[i] = acc;
+        x[i] = M[c][i];
+        y[i] = Bm[c][i];
       }
-      givens_rotate_in<N>(RL, x);
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        const double xj = x[j];
+        if (xj != 0.0) {
+          const double rjj = R[j][j];
+          const double h2 = fma(rjj, rjj, xj * xj);
+          const double inv = fast_rsqrt(h2);
+          const double cs = rjj * inv, sn = xj * inv;
+          R[j][j] = h2 * inv;
+#pragma unroll
+          for (int l = j + 1; l < N; ++l) {
+            const double rl = R[j][l], xl = x[l];
+            R[j][l] = cs * rl + sn * xl;
+            x[l] = cs * xl - sn * rl;
+          }
+#pragma unroll
+          for (int l = 0; l < N; ++l) {
+            const double rl = R12[j][l], yl = y[l];
+            R12[j][l] = cs * rl + sn * yl;
+            y[l] = cs * yl - sn * rl;
+          }
+        }
+      }
+      givens_rotate_in<N>(R22, y);
     }
+    // Gp^T = R^-1 R12 (back substitution; reciprocal pivots, 0 on an exactly singular factor)
+    double rinv[N];
 #pragma unroll
-    for (int c = 0; c < N; ++c) {
-      double x[N];
+    for (int j = 0; j < N; ++j) rinv[j] = (R[j][j] != 0.0) ? fast_rcp(R[j][j]) : 0.0;
+    double Gp[N][N];
 #pragma unroll
-      for (int i = 0; i < N; ++i) {
-        double acc = 0.0;
+    for (int q = 0; q < N; ++q) {
+      double zc[N];
 #pragma unroll
-        for (int k = c; k < N; ++k) acc += K.qsT[c][k] * Gp[i][k];
-        x[i] = sigma * acc;
+      for (int j = N - 1; j >= 0; --j) {
+        double acc = R12[j][q];
+#pragma unroll
+        for (int kk = j + 1; kk < N; ++kk) acc -= R[j][kk] * zc[kk];
+        zc[j] = acc * rinv[j];
       }
-      givens_rotate_in<N>(RL, x);
+#pragma unroll
+      for (int j = 0; j < N; ++j) Gp[q][j] = zc[j];
     }
     // back to plain coordinates
 #pragma unroll
@@ -134,7 +122,7 @@ __device__ __forceinline__ void iso_time_update(const IwpConst& K, const double 
 #pragma unroll
       for (int j = 0; j < N; ++j) {
         G[i][j] = p[i] * Gp[i][j] * pinv[j];
-        RL[i][j] *= p[j];
+        RL[i][j] = R22[i][j] * p[j];
       }
   }
 #pragma unroll
