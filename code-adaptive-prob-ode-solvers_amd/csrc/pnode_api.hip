@@ -313,6 +313,12 @@ int pnode_create(const pnode_config* cfg, pnode_batch** out) {
   if (!h->dense) {
     IsoView& v = h->iso;
     v.B = int(B); v.d = d; v.k = k; v.n = int(n); v.K = int(Kc);
+    {
+      int ncu = 0;
+      if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, cfg->device) != hipSuccess || ncu <= 0) ncu = 256;
+      v.cus = ncu;
+      v.fp_pipeline = 0;
+    }
     v.fixedpoint = cfg->strategy == PNODE_STRATEGY_FIXEDPOINT;
     v.dynamic = cfg->calibration == PNODE_CALIB_DYNAMIC;
     v.vf_id = cfg->vf_id; v.P = cfg->num_vf_params; v.prm_per_traj = cfg->vf_params_per_trajectory;
@@ -1271,6 +1277,13 @@ int pnode_set_generic_path(pnode_batch* h, int32_t enabled) {
   h->dn.user_generic = enabled == 1;
   h->dn.force_large = enabled == 2;
   h->dn.lq_two_launch = enabled == 3;
+  return PNODE_OK;
+}
+
+int pnode_set_smoother_pipeline(pnode_batch* h, int32_t mode) {
+  if (!h || mode < 0 || mode > 2) return fail(PNODE_EINVAL, "bad argument");
+  if (h->dense) return fail(PNODE_EINVAL, "the pipelined device controller belongs to the isotropic fixed-point smoother");
+  h->iso.fp_pipeline = mode;
   return PNODE_OK;
 }
 

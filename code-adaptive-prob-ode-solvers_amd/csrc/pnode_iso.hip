@@ -252,14 +252,14 @@ __device__ __forceinline__ void iso_store_regs(const IsoView& v, int b, int lane
 // One attempted step from the state `s`. Returns the normalised error norm.
 template <int N>
 __device__ __forceinline__ double iso_attempt_regs(const IsoView& v, const IwpConst& K, int b, int lane, double dt, double t,
-                                                   const IsoRegs<N>& s, IsoRegs<N>& o, double atol, double rtol, double* ybuf) {
+                                                   const IsoRegs<N>& s, IsoRegs<N>& o, double atol, double rtol, double* ybuf,
+                                                   double (&me)[N]) {
   const int d = v.d, k = v.k;
   const bool on = lane < d;
   double p[N], pinv[N];
   preconditioner<N>(dt, K, p, pinv);
 
-  // --- mean extrapolation  m^- = P Abar P^{-1} m
-  double me[N];
+  // --- mean extrapolation  m^- = P Abar P^{-1} m  (handed back: the fixed-point smoother's backward offset needs it)
   {
     double mp[N];
 #pragma unroll
@@ -348,7 +348,8 @@ __device__ __forceinline__ double iso_attempt(const IsoView& v, const IwpConst& 
     if (d <= kWave) {  // one column per lane: the register form above
       IsoRegs<N> s, o;
       iso_load_regs<N>(v, b, lane, arg.src, s);
-      const double e = iso_attempt_regs<N>(v, K, b, lane, arg.dt, arg.t, s, o, v.atol[b], v.rtol[b], ybuf);
+      double me[N];
+      const double e = iso_attempt_regs<N>(v, K, b, lane, arg.dt, arg.t, s, o, v.atol[b], v.rtol[b], ybuf, me);
       iso_store_regs<N>(v, b, lane, arg.dst, o);
       return e;
     }
@@ -563,7 +564,8 @@ __global__ __launch_bounds__(256) void iso_advance_kernel(IsoView v, TrajCtl* __
         double dt = c.dt;
         if (cp.clip) dt = fmin(dt, c.t_stop - c.t_sf);
         IsoRegs<N> nw;
-        const double e = iso_attempt_regs<N>(v, K, b, lane, dt, c.t_sf, cur, nw, atol, rtol, ybuf);
+        double me[N];
+        const double e = iso_attempt_regs<N>(v, K, b, lane, dt, c.t_sf, cur, nw, atol, rtol, ybuf, me);
         ++iters;
         const int dst = c.s_pr;
         if (iso_after_attempt(c, cp, e, dt)) {
@@ -589,6 +591,208 @@ __global__ __launch_bounds__(256) void iso_advance_kernel(IsoView v, TrajCtl* __
   }
   if (c.status == 0) c.status = (c.t_sf + cp.numerical_zero >= c.t_stop) ? 1 : 3;
   if (lane == 0) ctl[b] = c;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Device-resident controller of the FIXED-POINT SMOOTHER, d <= 64: one workgroup of four wavefronts per trajectory.
+// An attempt of the smoother is the filter's attempt plus the backward transition of the step and its composition with the
+// running transition (ivpsolvers.py:43) -- four fifths of the instructions, none of which the controller's decision needs.
+// Wavefront 0 runs the filter and the controller exactly like iso_advance_kernel (state in registers, 5 us per attempt); every
+// ACCEPTED step goes into a ring in LDS (previous factor and mean, extrapolated mean, dt, sigma, destination slot). The
+// wavefronts 1..3 take the steps a = w - 1, w + 2, .. : the transition of a step (iso_time_update<N, true>) depends on that
+// step alone, so three are in flight; the compositions are chained through the running transition in LDS (mergedS), which is
+// written to the step's slot as it goes: at the end of the launch STEP_FROM and INTERP_FROM hold theirs, as the host-driven
+// path leaves them. Same arithmetic, expression by expression, as iso_attempt<N, true, 1>. Every wait is a bounded spin.
+// ---------------------------------------------------------------------------------------------
+constexpr int kFpRing = 4;
+constexpr int kFpSpin = 1 << 22;
+using lds_word = __attribute__((address_space(3))) int;
+
+template <int N>
+__host__ __device__ constexpr int iso_fp_entry_doubles() { return N * N + 2 * N * kWave + 4; }
+__host__ __device__ inline size_t iso_fp_shm_doubles(int n, int k, int d) {
+  return size_t(k) * d + size_t(kFpRing) * (size_t(n) * n + 2 * size_t(n) * kWave + 4) + 2 * size_t(n) * n + size_t(n) * kWave + 8;
+}
+
+template <int N>
+__global__ __launch_bounds__(256) void iso_advance_fp_kernel(IsoView v, TrajCtl* __restrict__ ctl, const IwpConst* __restrict__ Kc,
+                                                             ControlParams cp) {
+  extern __shared__ double smem[];
+  constexpr int EN = iso_fp_entry_doubles<N>();
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x;
+  if (b >= v.B) return;
+  TrajCtl c = ctl[b];
+  if (c.status < 0) return;  // (uniform over the workgroup)
+  const IwpConst& K = *Kc;
+  const int d = v.d, k = v.k;
+  const size_t sB = size_t(v.B);
+  double* ybuf = smem;                         // [k][d]
+  double* ring = ybuf + size_t(k) * d;         // [kFpRing][EN]: R_prev [N][N] | m_prev [N][64] | m^- [N][64] | dt, sigma, dst
+  double* runG = ring + kFpRing * EN;          // running transition of the last merged step: G [N][N], RL [N][N], xi [N][64]
+  double* runL = runG + N * N;
+  double* runX = runL + N * N;
+  int* flags = reinterpret_cast<int*>(runX + N * kWave);  // pushed, merged, total (-1: still running), abort
+  volatile lds_word* pushedS = (volatile lds_word*)&flags[0];
+  volatile lds_word* mergedS = (volatile lds_word*)&flags[1];
+  volatile lds_word* totalS = (volatile lds_word*)&flags[2];
+  volatile lds_word* abortS = (volatile lds_word*)&flags[3];
+  if (tid == 0) {
+    flags[0] = 0;
+    flags[1] = 0;
+    flags[2] = -1;
+    flags[3] = 0;
+  }
+  if (wv == 1) {  // the running transition of STEP_FROM
+    for (int e = lane; e < N * N; e += kWave) {
+      runG[e] = v.cG[(size_t(c.s_sf) * sB + b) * N * N + e];
+      runL[e] = v.cLam[(size_t(c.s_sf) * sB + b) * N * N + e];
+    }
+    const double* xi0 = v.cxi + (size_t(c.s_sf) * sB + b) * N * d;
+#pragma unroll
+    for (int i = 0; i < N; ++i) runX[i * kWave + lane] = lane < d ? xi0[i * d + lane] : 0.0;
+  }
+  __syncthreads();  // the only workgroup barrier
+  auto lds_done = [] { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+
+  if (wv == 0) {
+    // ---------------- filter + controller (iso_advance_kernel's loop), accepted steps handed to the ring
+    int iters = 0, acc = 0;
+    c.status = 0;
+    const double atol = v.atol[b], rtol = v.rtol[b];
+    IsoRegs<N> cur;
+    iso_load_regs<N>(v, b, lane, c.s_sf, cur);
+    while (c.t_sf + cp.numerical_zero < c.t_stop && iters < cp.max_iters) {
+      double dt = c.dt;
+      if (cp.clip) dt = fmin(dt, c.t_stop - c.t_sf);
+      IsoRegs<N> nw;
+      double me[N];
+      const double e = iso_attempt_regs<N>(v, K, b, lane, dt, c.t_sf, cur, nw, atol, rtol, ybuf, me);
+      ++iters;
+      const int dst = c.s_pr;
+      if (iso_after_attempt(c, cp, e, dt)) {
+        int n = 0;
+        while (acc - __builtin_amdgcn_readfirstlane(*mergedS) >= kFpRing) {  // ring full: the smoother is behind
+          __builtin_amdgcn_s_sleep(4);
+          if (++n > kFpSpin || __builtin_amdgcn_readfirstlane(*abortS)) {
+            *abortS = 1;
+            break;
+          }
+        }
+        double* ent = ring + (acc % kFpRing) * EN;
+        store_small<N>(ent, cur.R, lane);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+          ent[N * N + i * kWave + lane] = cur.m[i];
+          ent[N * N + N * kWave + i * kWave + lane] = me[i];
+        }
+        if (lane == 0) {
+          ent[EN - 4] = dt;
+          ent[EN - 3] = nw.sigma;
+          ent[EN - 2] = double(dst);
+        }
+        lds_done();
+        ++acc;
+        if (lane == 0) *pushedS = acc;
+        iso_store_regs<N>(v, b, lane, dst, nw);
+        cur = nw;
+      }
+      if (c.status == 2) break;
+      if (__builtin_amdgcn_readfirstlane(*abortS)) {
+        c.status = 2;
+        break;
+      }
+    }
+    if (c.status == 0) c.status = (c.t_sf + cp.numerical_zero >= c.t_stop) ? 1 : 3;
+    if (lane == 0) {
+      *totalS = acc;
+      ctl[b] = c;
+    }
+  } else {
+    // ---------------- backward transitions of the accepted steps a = wv - 1, wv + 2, .. and their composition in order
+#pragma unroll 1
+    for (int a = wv - 1;; a += 3) {
+      int n = 0;
+      bool have = true;
+      while (__builtin_amdgcn_readfirstlane(*pushedS) <= a) {
+        const int tot = __builtin_amdgcn_readfirstlane(*totalS);
+        if (tot >= 0 && a >= tot) {
+          have = false;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(4);
+        if (++n > kFpSpin || __builtin_amdgcn_readfirstlane(*abortS)) {
+          *abortS = 1;
+          have = false;
+          break;
+        }
+      }
+      if (!have) break;
+      asm volatile("" ::: "memory");
+      const double* ent = ring + (a % kFpRing) * EN;
+      double Rprev[N][N], Rm[N][N], G[N][N], RL[N][N];
+      load_small<N>(ent, Rprev);
+      const double dt = ent[EN - 4], sigma = ent[EN - 3];
+      const int dst = int(ent[EN - 2]);
+      double mprev[N], me[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        mprev[i] = ent[N * N + i * kWave + lane];
+        me[i] = ent[N * N + N * kWave + i * kWave + lane];
+      }
+      double p[N], pinv[N];
+      preconditioner<N>(dt, K, p, pinv);
+      iso_time_update<N, true>(K, Rprev, p, pinv, sigma, Rm, G, RL);
+      double xi[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        double s = mprev[i];
+#pragma unroll
+        for (int kk = 0; kk < N; ++kk) s -= G[i][kk] * me[kk];
+        xi[i] = s;
+      }
+      // composition with the running transition: in the order of the steps
+      n = 0;
+      bool ok = true;
+      while (__builtin_amdgcn_readfirstlane(*mergedS) < a) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++n > kFpSpin || __builtin_amdgcn_readfirstlane(*abortS)) {
+          *abortS = 1;
+          ok = false;
+          break;
+        }
+      }
+      if (!ok) break;
+      asm volatile("" ::: "memory");
+      double G0[N][N], RL0[N][N];
+      load_small<N>(runG, G0);
+      load_small<N>(runL, RL0);
+      double xn[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        double s = runX[i * kWave + lane];
+#pragma unroll
+        for (int kk = 0; kk < N; ++kk) s += G0[i][kk] * xi[kk];
+        xn[i] = s;
+      }
+      iso_merge_small<N>(G0, RL0, G, RL);
+      lds_done();  // (my reads of the running transition are complete before it is overwritten)
+      store_small<N>(runG, G, lane);
+      store_small<N>(runL, RL, lane);
+#pragma unroll
+      for (int i = 0; i < N; ++i) runX[i * kWave + lane] = xn[i];
+      double* xid = v.cxi + (size_t(dst) * sB + b) * N * d;
+      if (lane < d) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) xid[i * d + lane] = xn[i];
+      }
+      store_small<N>(v.cG + (size_t(dst) * sB + b) * N * N, G, lane);
+      store_small<N>(v.cLam + (size_t(dst) * sB + b) * N * N, RL, lane);
+      lds_done();
+      if (lane == 0) *mergedS = a + 1;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1033,6 +1237,14 @@ static void launch_advance_n(const IsoView& v, TrajCtl* ctl, const IwpConst* K, 
     return;
   }
   const int blocks = (v.B + 3) / 4;
+  // Fixed-point smoother, d <= 64: a workgroup per trajectory (filter wavefront + three smoother wavefronts) shortens the chain of
+  // a trajectory 1.6x but holds a CU; with more trajectories than CUs and equal work per trajectory the one-wavefront kernel
+  // (four trajectories per workgroup, every SIMD busy) has the higher throughput. Both produce the same bits.
+  const bool pipelined = v.fp_pipeline == 1 || (v.fp_pipeline == 0 && v.B <= v.cus);
+  if (v.fixedpoint && v.d <= kWave && pipelined) {
+    hipLaunchKernelGGL((iso_advance_fp_kernel<N>), dim3(v.B), dim3(256), iso_fp_shm_doubles(N, v.k, v.d) * sizeof(double), s, v, ctl, K, cp);
+    return;
+  }
   if (v.fixedpoint)
     hipLaunchKernelGGL((iso_advance_kernel<N, true, 1>), dim3(blocks), dim3(256), iso_shm(v, 4), s, v, ctl, K, cp);
   else

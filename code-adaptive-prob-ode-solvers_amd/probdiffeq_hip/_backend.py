@@ -24,7 +24,7 @@ SYMBOLS = (
     "pnode_set_tolerances pnode_attempt_step pnode_user_extrapolate pnode_user_set_vf pnode_commit pnode_interpolate pnode_checkpoint_at_step "
     "pnode_solve_fixed_grid pnode_solve_adaptive_save_at pnode_solve_adaptive_save_at_device pnode_read_mean pnode_read_time pnode_read_output_scale pnode_read_factor "
     "pnode_read_checkpoint_means pnode_read_checkpoint_factors pnode_smooth_checkpoint_means pnode_last_step_ms pnode_set_phase_timing "
-    "pnode_last_phase_ms pnode_set_generic_path pnode_stream pnode_advance_device pnode_debug_set_lq_spin_limit pnode_phase_ms_mean pnode_sample_checkpoints_n"
+    "pnode_last_phase_ms pnode_set_generic_path pnode_stream pnode_advance_device pnode_debug_set_lq_spin_limit pnode_phase_ms_mean pnode_sample_checkpoints_n pnode_set_smoother_pipeline"
 ).split()
 
 
@@ -114,6 +114,7 @@ def load_library():
     lib.pnode_last_step_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.pnode_set_phase_timing.argtypes = [vp, C.c_int32]
     lib.pnode_set_generic_path.argtypes = [vp, C.c_int32]
+    lib.pnode_set_smoother_pipeline.argtypes = [vp, C.c_int32]
     lib.pnode_debug_set_lq_spin_limit.argtypes = [vp, C.c_int32]
     lib.pnode_last_phase_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.pnode_phase_ms_mean.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int64)]
@@ -381,6 +382,10 @@ class Batch:
         _check(self._lib.pnode_sample_checkpoints_n(self._h, nf.ctypes.data_as(C.POINTER(C.c_int32)), eps.shape[2], eps.shape[1],
                                                     _dp(eps), _dp(out)))
         return out
+
+    def set_smoother_pipeline(self, mode):
+        """0 by batch size, 1 workgroup per trajectory (pipelined), 2 wavefront per trajectory (include/pnode.h)."""
+        _check(self._lib.pnode_set_smoother_pipeline(self._h, int(mode)))
 
     def set_generic_path(self, enabled=True):
         _check(self._lib.pnode_set_generic_path(self._h, int(enabled)))

@@ -261,7 +261,11 @@ def solve_adaptive_save_at(vector_field, initial_condition: InitialCondition, sa
 
     Controller placement: by default the PI controller and the accept/reject decisions run on the host (native
     loop inside the C-ABI; `python_controller=True` runs the same loop in NumPy). `device_controller=True`
-    (isotropic model, or dense model with (nu+1) d <= 32) moves them into the step kernel: one host synchronisation per checkpoint interval.
+    moves them to the device: one host synchronisation per checkpoint interval (isotropic model, dense model with (nu+1) d <= 32: inside
+    the step kernel; the other dense paths: a controller kernel between the attempts). For the isotropic fixed-point smoother with
+    d <= 64 there are two such kernels with identical results: `device_controller="pipelined"` (a workgroup per trajectory, the backward
+    transitions beside the filter: shortest chain per trajectory) and `"one-wavefront"` (highest throughput for a batch of equal
+    trajectories that fills the device); `True` chooses by the batch size (include/pnode.h, pnode_set_smoother_pipeline).
     """
     solver = adaptive_solver.solver
     if not solver.strategy.is_suitable_for_save_at:
@@ -277,6 +281,12 @@ def solve_adaptive_save_at(vector_field, initial_condition: InitialCondition, sa
     batch = _make_batch(vector_field, init, solver, K, device, checkpoint_factors)
     batch.set_initial(init.tcoeffs, sa_b[:, 0], init.output_scale)
     batch.set_tolerances(adaptive_solver.atol, adaptive_solver.rtol)
+    if isinstance(device_controller, str):
+        if device_controller not in ("pipelined", "one-wavefront"):
+            raise ValueError("device_controller: True, False, 'pipelined' or 'one-wavefront'")
+        if solver.strategy.model == "isotropic":
+            batch.set_smoother_pipeline(1 if device_controller == "pipelined" else 2)
+        device_controller = True
     loop = _AdaptiveLoop(batch, adaptive_solver, sa_b[:, 0], dt0, vf=vector_field)
     if python_controller or loop.user_vf is not None:
         cursor, num_steps = _python_save_at_loop(batch, loop, sa_b, K, adaptive_solver.numerical_zero)

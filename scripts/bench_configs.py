@@ -46,7 +46,7 @@ def run(name, vf, u0s, t0, t1, *, model, corr, strategy, nu, atol, rtol, dt0, nu
     att = int(np.sum(sol.num_attempts))
     B = init.tcoeffs.shape[0]
     out = {"config": name, "batch": B, "d": d, "nu": nu, "model": model, "correction": corr, "strategy": strategy,
-           "controller": "device" if device_controller else "host",
+           "controller": ("device (" + device_controller + ")" if isinstance(device_controller, str) else "device") if device_controller else "host",
            "accepted_steps": acc, "attempted_steps": att, "seconds": round(el, 4),
            "accepted_steps_per_s": acc / el, "finite": bool(np.all(np.isfinite(sol.u)))}
     if truth is not None:
@@ -156,11 +156,15 @@ def main():
     run("C4 brusselator iso EKF0 nu=4 fixedpoint 200 ckpts", vf, [y0], 0.0, 10.0, model="isotropic", corr="ts0",
         strategy="fixedpoint", nu=4, atol=1e-8, rtol=1e-8, dt0=0.01, num_save=200, device_controller=True)
     vf, u0, (t0, t1), _ = ivps.rigid_body(time_span=(0.0, 50.0))
-    run("C3 rigid body nu=3 sweep", vf, [np.tile(u0[0], (B, 1))], t0, t1, model="isotropic", corr="ts0",
-        strategy="fixedpoint", nu=3, atol=1e-3 * rt, rtol=rt, dt0=0.1, device_controller=True)
+    # (tolerance sweeps are bound by their slowest members: both kernels of the smoother's device controller; `True` would pick
+    # the one-wavefront kernel for 1024 > #CUs trajectories)
+    for dc in (True, "pipelined"):
+        run("C3 rigid body nu=3 sweep", vf, [np.tile(u0[0], (B, 1))], t0, t1, model="isotropic", corr="ts0",
+            strategy="fixedpoint", nu=3, atol=1e-3 * rt, rtol=rt, dt0=0.1, device_controller=dc)
     vf, u0, (t0, t1) = ivps.pleiades_2nd()
-    run("C3 pleiades nu=3 sweep", vf, [np.tile(u0[0], (B, 1)), np.tile(u0[1], (B, 1))], t0, t1, model="isotropic",
-        corr="ts0", strategy="fixedpoint", nu=3, atol=1e-3 * rt, rtol=rt, dt0=0.01, device_controller=True)
+    for dc in (True, "pipelined"):
+        run("C3 pleiades nu=3 sweep", vf, [np.tile(u0[0], (B, 1)), np.tile(u0[1], (B, 1))], t0, t1, model="isotropic",
+            corr="ts0", strategy="fixedpoint", nu=3, atol=1e-3 * rt, rtol=rt, dt0=0.01, device_controller=dc)
     vf, u0, (t0, t1), _ = ivps.van_der_pol_first_order(1.0)
     run("C1 vdp mu=1 (single)", vf, [u0[0]], t0, t1, model="isotropic", corr="ts0", strategy="filter", nu=3,
         atol=1e-6, rtol=1e-6, dt0=0.1, device_controller=True)

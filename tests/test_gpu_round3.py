@@ -314,3 +314,30 @@ def test_device_resident_controller_of_the_dense_fixedpoint_smoother(hip_lib, N)
     status, attempts = batch.advance_device(np.full(B, np.inf), dt, lp, asolver.control, asolver.numerical_zero, 3)
     assert np.all(status == 0) and np.all(attempts == 3)
     batch.close()
+
+
+def test_two_device_controllers_of_the_isotropic_fixedpoint_smoother_agree(hip_lib):
+    """The device-resident controller of the isotropic fixed-point smoother (ivpsolvers.py:43) exists as two kernels: one wavefront
+    per trajectory (iso_advance_kernel) and one workgroup per trajectory with the backward transitions of the accepted steps on
+    three wavefronts beside the filter (iso_advance_fp_kernel; chosen for batches of at most #CUs trajectories). Same expressions
+    in the same order: identical decisions and identical smoothed means, bit for bit, and both equal to the host controller's
+    decisions (Brusselator N = 8, nu = 4 as in experiment 4, a tolerance sweep so that the trajectories differ)."""
+    N, B = 8, 6
+    vf = V.brusselator(N)
+    y0 = np.stack([brusselator_y0(N, 0.5 * b) for b in range(B)])
+    impl.select("isotropic", ode_shape=(2 * N,))
+    solver = ivpsolvers.solver_dynamic(ivpsolvers.strategy_fixedpoint(ivpsolvers.prior_ibm(4), ivpsolvers.correction_ts0()))
+    tol = 10.0 ** -np.linspace(3, 7, B)
+    asolver = ivpsolve.adaptive(solver, atol=tol, rtol=tol)
+    init = solver.initial_condition(taylor.odejet_padded_scan(vf, [y0], num=4), 1.0)
+    save_at = np.linspace(0.0, 2.0, 9)
+    run = lambda dc: ivpsolve.solve_adaptive_save_at(vf, init, save_at=save_at, dt0=0.01, adaptive_solver=asolver, device_controller=dc)
+    host, pipe, one, auto = run(False), run("pipelined"), run("one-wavefront"), run(True)
+    assert host.num_steps[:, -1].min() >= 10 and len(set(host.num_steps[:, -1])) > 1
+    for dev in (pipe, one, auto):
+        assert np.array_equal(dev.num_steps, host.num_steps)
+        assert np.array_equal(dev.num_attempts, host.num_attempts)
+        assert relmax(dev.u, host.u) < 1e-11
+    assert np.array_equal(pipe.u, one.u) and np.array_equal(auto.u, pipe.u)
+    with pytest.raises(ValueError):
+        run("something else")
