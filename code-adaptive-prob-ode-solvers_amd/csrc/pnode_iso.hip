@@ -1238,9 +1238,19 @@ static void launch_advance_n(const IsoView& v, TrajCtl* ctl, const IwpConst* K, 
   }
   const int blocks = (v.B + 3) / 4;
   // Fixed-point smoother, d <= 64: a workgroup per trajectory (filter wavefront + three smoother wavefronts) shortens the chain of
-  // a trajectory 1.6x but holds a CU; with more trajectories than CUs and equal work per trajectory the one-wavefront kernel
+  // a trajectory 1.6x but holds a CU (two fit up to nu = 3); with more trajectories than fit at once and equal work per trajectory the one-wavefront kernel
   // (four trajectories per workgroup, every SIMD busy) has the higher throughput. Both produce the same bits.
-  const bool pipelined = v.fp_pipeline == 1 || (v.fp_pipeline == 0 && v.B <= v.cus);
+  bool pipelined = v.fp_pipeline == 1;
+  if (v.fixedpoint && v.d <= kWave && v.fp_pipeline == 0) {  // by batch size: every trajectory resident at once
+    static int occ = -1;  // workgroups of this kernel (this N) per CU
+    if (occ < 0) {
+      int nb = 0;
+      const size_t shm = iso_fp_shm_doubles(N, v.k, v.d) * sizeof(double);
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, iso_advance_fp_kernel<N>, 256, shm) != hipSuccess || nb < 1) nb = 1;
+      occ = nb;
+    }
+    pipelined = v.B <= v.cus * occ;
+  }
   if (v.fixedpoint && v.d <= kWave && pipelined) {
     hipLaunchKernelGGL((iso_advance_fp_kernel<N>), dim3(v.B), dim3(256), iso_fp_shm_doubles(N, v.k, v.d) * sizeof(double), s, v, ctl, K, cp);
     return;

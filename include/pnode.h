@@ -226,8 +226,8 @@ int pnode_set_generic_path(pnode_batch* h, int32_t enabled);
  * (pnode_solve_adaptive_save_at_device): which of two kernels runs the attempts of a checkpoint interval. 1 = one workgroup per
  * trajectory, the filter and the controller on one wavefront and the backward transitions of the accepted steps on three others
  * (the chain of one trajectory is 1.6x shorter: single trajectories, tolerance sweeps, anything bound by its slowest member);
- * 2 = one wavefront per trajectory (highest throughput when the batch fills the device with equal work); 0 (default) = 1 when the
- * batch has no more trajectories than the device has compute units, else 2. Both kernels evaluate the same expressions in the
+ * 2 = one wavefront per trajectory (highest throughput when the batch fills the device with equal work); 0 (default) = 1 when
+ * every trajectory of the batch can be resident at once (#CUs x workgroups of that kernel per CU), else 2. Both kernels evaluate the same expressions in the
  * same order: the results do not depend on the choice. */
 int pnode_set_smoother_pipeline(pnode_batch* h, int32_t mode);
 /* Diagnostics of the one-launch LQ of the dense MFMA path (csrc/pnode_dense_lq4.hip): its wavefronts hand panels over through
