@@ -1239,7 +1239,8 @@ static void launch_advance_n(const IsoView& v, TrajCtl* ctl, const IwpConst* K, 
   const int blocks = (v.B + 3) / 4;
   // Fixed-point smoother, d <= 64: a workgroup per trajectory (filter wavefront + three smoother wavefronts) shortens the chain of
   // a trajectory 1.6x but holds a CU (two fit up to nu = 3); with more trajectories than fit at once and equal work per trajectory the one-wavefront kernel
-  // (four trajectories per workgroup, every SIMD busy) has the higher throughput. Both produce the same bits.
+  // (four trajectories per workgroup, every SIMD busy) has the higher throughput. Both take the same decisions bit for bit (the filter arithmetic is the same code); the smoothed
+  // means agree to rounding (the compiler contracts the multiply-adds of the transitions differently in the two kernels).
   bool pipelined = v.fp_pipeline == 1;
   if (v.fixedpoint && v.d <= kWave && v.fp_pipeline == 0) {  // by batch size: every trajectory resident at once
     static int occ = -1;  // workgroups of this kernel (this N) per CU

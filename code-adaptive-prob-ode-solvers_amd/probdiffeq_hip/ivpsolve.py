@@ -263,7 +263,7 @@ def solve_adaptive_save_at(vector_field, initial_condition: InitialCondition, sa
     loop inside the C-ABI; `python_controller=True` runs the same loop in NumPy). `device_controller=True`
     moves them to the device: one host synchronisation per checkpoint interval (isotropic model, dense model with (nu+1) d <= 32: inside
     the step kernel; the other dense paths: a controller kernel between the attempts). For the isotropic fixed-point smoother with
-    d <= 64 there are two such kernels with identical results: `device_controller="pipelined"` (a workgroup per trajectory, the backward
+    d <= 64 there are two such kernels with identical decisions (smoothed means equal to rounding): `device_controller="pipelined"` (a workgroup per trajectory, the backward
     transitions beside the filter: shortest chain per trajectory) and `"one-wavefront"` (highest throughput for a batch of equal
     trajectories that fills the device); `True` chooses by the batch size (include/pnode.h, pnode_set_smoother_pipeline).
     """

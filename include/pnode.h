@@ -228,7 +228,8 @@ int pnode_set_generic_path(pnode_batch* h, int32_t enabled);
  * (the chain of one trajectory is 1.6x shorter: single trajectories, tolerance sweeps, anything bound by its slowest member);
  * 2 = one wavefront per trajectory (highest throughput when the batch fills the device with equal work); 0 (default) = 1 when
  * every trajectory of the batch can be resident at once (#CUs x workgroups of that kernel per CU), else 2. Both kernels evaluate the same expressions in the
- * same order: the results do not depend on the choice. */
+ * same order: the controller's decisions (accepted steps, step sizes) are identical bit for bit, the smoothed means agree to
+ * rounding (1e-13 relative: multiply-adds of the backward transitions are contracted differently by the compiler). */
 int pnode_set_smoother_pipeline(pnode_batch* h, int32_t mode);
 /* Diagnostics of the one-launch LQ of the dense MFMA path (csrc/pnode_dense_lq4.hip): its wavefronts hand panels over through
  * flag words in LDS, and every wait is a bounded spin. A wait that runs into its bound is reported by the call that synchronises

@@ -320,8 +320,8 @@ def test_two_device_controllers_of_the_isotropic_fixedpoint_smoother_agree(hip_l
     """The device-resident controller of the isotropic fixed-point smoother (ivpsolvers.py:43) exists as two kernels: one wavefront
     per trajectory (iso_advance_kernel) and one workgroup per trajectory with the backward transitions of the accepted steps on
     three wavefronts beside the filter (iso_advance_fp_kernel; chosen for batches of at most #CUs trajectories). Same expressions
-    in the same order: identical decisions and identical smoothed means, bit for bit, and both equal to the host controller's
-    decisions (Brusselator N = 8, nu = 4 as in experiment 4, a tolerance sweep so that the trajectories differ)."""
+    in the same order: identical decisions bit for bit -- also the host controller's -- and smoothed means equal to rounding (the
+    multiply-adds of the transitions are contracted differently in the two kernels) (Brusselator N = 8, nu = 4 as in experiment 4, a tolerance sweep so that the trajectories differ)."""
     N, B = 8, 6
     vf = V.brusselator(N)
     y0 = np.stack([brusselator_y0(N, 0.5 * b) for b in range(B)])
@@ -338,6 +338,33 @@ def test_two_device_controllers_of_the_isotropic_fixedpoint_smoother_agree(hip_l
         assert np.array_equal(dev.num_steps, host.num_steps)
         assert np.array_equal(dev.num_attempts, host.num_attempts)
         assert relmax(dev.u, host.u) < 1e-11
-    assert np.array_equal(pipe.u, one.u) and np.array_equal(auto.u, pipe.u)
+    assert relmax(pipe.u, one.u) < 1e-12 and np.array_equal(auto.u, pipe.u)
     with pytest.raises(ValueError):
         run("something else")
+
+
+def test_pipelined_smoother_controller_with_a_diverging_member(hip_lib):
+    """Failure path of the pipelined device controller (iso_advance_fp_kernel): a member whose ODE blows up in finite time
+    (u' = u (1 + 5 u), blow-up at t = log(6/5)) beside two healthy ones on ragged save_at grids. The three controllers -- host,
+    one wavefront per trajectory, pipelined -- report the same step counts, flag the same member, and leave the neighbours'
+    smoothed means identical (the reference propagates NaNs, vdp.py:107-108)."""
+    vfb = V.VectorField(V.VF_LOGISTIC, 1, 1, np.array([[1.0, 1.0], [1.0, -5.0], [1.0, 1.0]]), "logistic")
+    impl.select("isotropic", ode_shape=(1,))
+    u0 = np.array([[0.1], [1.0], [0.3]])
+    bb = np.array([[1.0], [-5.0], [1.0]])
+    tcs = [u0, u0 * (1 - bb * u0)]
+    tcs.append(tcs[1] * (1 - 2 * bb * u0))
+    fp = ivpsolvers.solver_dynamic(ivpsolvers.strategy_fixedpoint(ivpsolvers.prior_ibm(2), ivpsolvers.correction_ts0()))
+    init = fp.initial_condition(tcs, 1.0)
+    save_at = np.stack([np.linspace(0.0, 2.0, 4), np.linspace(0.0, 1.0, 4), np.linspace(0.0, 3.0, 4)])
+    asolver = ivpsolve.adaptive(fp, atol=1e-8, rtol=1e-6)
+    run = lambda dc: ivpsolve.solve_adaptive_save_at(vfb, init, save_at=save_at, dt0=0.05, adaptive_solver=asolver, device_controller=dc)
+    host, one, pipe = run(False), run("one-wavefront"), run("pipelined")
+    ex = lambda u, t: u * np.exp(t) / (1.0 + u * (np.exp(t) - 1.0))  # noqa: E731
+    for sol in (host, one, pipe):
+        assert abs(sol.u[0, -1, 0] - ex(0.1, 2.0)) < 1e-4 and abs(sol.u[2, -1, 0] - ex(0.3, 3.0)) < 1e-4
+        assert not np.all(np.isfinite(sol.u[1])) or np.max(np.abs(sol.u[1])) > 1e3
+    assert np.array_equal(one.num_steps, pipe.num_steps) and np.array_equal(one.num_steps[[0, 2]], host.num_steps[[0, 2]])
+    assert relmax(one.u[[0, 2]], pipe.u[[0, 2]]) < 1e-12
+    assert np.array_equal(np.isnan(one.u), np.isnan(pipe.u))
+    assert relmax(one.u[[0, 2]], host.u[[0, 2]]) < 1e-11
