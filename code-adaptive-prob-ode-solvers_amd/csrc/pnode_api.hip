@@ -1281,7 +1281,7 @@ int pnode_set_generic_path(pnode_batch* h, int32_t enabled) {
 }
 
 int pnode_set_smoother_pipeline(pnode_batch* h, int32_t mode) {
-  if (!h || mode < 0 || mode > 2) return fail(PNODE_EINVAL, "bad argument");
+  if (!h || mode < 0 || mode > 1) return fail(PNODE_EINVAL, "bad argument");
   if (h->dense) return fail(PNODE_EINVAL, "the pipelined device controller belongs to the isotropic fixed-point smoother");
   h->iso.fp_pipeline = mode;
   return PNODE_OK;

@@ -9,7 +9,7 @@ struct IsoView {
   int B, d, k, n, K;  // batch, ODE dim, ode order, nu+1, checkpoint capacity
   int fixedpoint, dynamic, vf_id, P, prm_per_traj;
   int cus;          // compute units of the device
-  int fp_pipeline;  // device-resident controller of the fixed-point smoother: 0 by batch size, 1 pipelined kernel, 2 one-wavefront kernel
+  int fp_pipeline;  // device-resident controller of the fixed-point smoother: 0 one wavefront per trajectory, 1 pipelined (workgroup per trajectory)
   double* mean;   // [3][B][n][d]
   double* fac;    // [3][B][n][n]   Sigma = fac^T fac
   double* cG;     // [3][B][n][n]   running backward transition (fixedpoint)

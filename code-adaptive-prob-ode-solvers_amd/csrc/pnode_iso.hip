@@ -1237,21 +1237,13 @@ static void launch_advance_n(const IsoView& v, TrajCtl* ctl, const IwpConst* K, 
     return;
   }
   const int blocks = (v.B + 3) / 4;
-  // Fixed-point smoother, d <= 64: a workgroup per trajectory (filter wavefront + three smoother wavefronts) shortens the chain of
-  // a trajectory 1.6x but holds a CU (two fit up to nu = 3); with more trajectories than fit at once and equal work per trajectory the one-wavefront kernel
-  // (four trajectories per workgroup, every SIMD busy) has the higher throughput. Both take the same decisions bit for bit (the filter arithmetic is the same code); the smoothed
-  // means agree to rounding (the compiler contracts the multiply-adds of the transitions differently in the two kernels).
-  bool pipelined = v.fp_pipeline == 1;
-  if (v.fixedpoint && v.d <= kWave && v.fp_pipeline == 0) {  // by batch size: every trajectory resident at once
-    static int occ = -1;  // workgroups of this kernel (this N) per CU
-    if (occ < 0) {
-      int nb = 0;
-      const size_t shm = iso_fp_shm_doubles(N, v.k, v.d) * sizeof(double);
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, iso_advance_fp_kernel<N>, 256, shm) != hipSuccess || nb < 1) nb = 1;
-      occ = nb;
-    }
-    pipelined = v.B <= v.cus * occ;
-  }
+  // Fixed-point smoother, d <= 64, on request (pnode_set_smoother_pipeline): a workgroup per trajectory (filter wavefront + three
+  // smoother wavefronts) shortens the chain of a trajectory 1.6x but holds a CU (two fit up to nu = 3); with more trajectories than fit
+  // at once and equal work per trajectory the one-wavefront kernel (four trajectories per workgroup, every SIMD busy) has the
+  // higher throughput. Both take the same decisions bit for bit (the filter arithmetic is the same code); the smoothed means agree
+  // to rounding (the compiler contracts the multiply-adds of the transitions differently in the two kernels) -- which is why the
+  // choice is the caller's and never made from the batch size: a shard of a batch gives the bits of the unsharded solve.
+  const bool pipelined = v.fp_pipeline == 1;
   if (v.fixedpoint && v.d <= kWave && pipelined) {
     hipLaunchKernelGGL((iso_advance_fp_kernel<N>), dim3(v.B), dim3(256), iso_fp_shm_doubles(N, v.k, v.d) * sizeof(double), s, v, ctl, K, cp);
     return;

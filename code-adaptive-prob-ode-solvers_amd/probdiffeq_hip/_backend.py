@@ -384,7 +384,7 @@ class Batch:
         return out
 
     def set_smoother_pipeline(self, mode):
-        """0 by batch size, 1 workgroup per trajectory (pipelined), 2 wavefront per trajectory (include/pnode.h)."""
+        """0 wavefront per trajectory (default), 1 workgroup per trajectory (pipelined); include/pnode.h."""
         _check(self._lib.pnode_set_smoother_pipeline(self._h, int(mode)))
 
     def set_generic_path(self, enabled=True):

@@ -264,8 +264,8 @@ def solve_adaptive_save_at(vector_field, initial_condition: InitialCondition, sa
     moves them to the device: one host synchronisation per checkpoint interval (isotropic model, dense model with (nu+1) d <= 32: inside
     the step kernel; the other dense paths: a controller kernel between the attempts). For the isotropic fixed-point smoother with
     d <= 64 there are two such kernels with identical decisions (smoothed means equal to rounding): `device_controller="pipelined"` (a workgroup per trajectory, the backward
-    transitions beside the filter: shortest chain per trajectory) and `"one-wavefront"` (highest throughput for a batch of equal
-    trajectories that fills the device); `True` chooses by the batch size (include/pnode.h, pnode_set_smoother_pipeline).
+    transitions beside the filter: shortest chain per trajectory -- single trajectories, tolerance sweeps) and `"one-wavefront"` (= `True`,
+    the default: highest throughput for a batch of equal trajectories that fills the device); include/pnode.h, pnode_set_smoother_pipeline.
     """
     solver = adaptive_solver.solver
     if not solver.strategy.is_suitable_for_save_at:
@@ -285,7 +285,7 @@ def solve_adaptive_save_at(vector_field, initial_condition: InitialCondition, sa
         if device_controller not in ("pipelined", "one-wavefront"):
             raise ValueError("device_controller: True, False, 'pipelined' or 'one-wavefront'")
         if solver.strategy.model == "isotropic":
-            batch.set_smoother_pipeline(1 if device_controller == "pipelined" else 2)
+            batch.set_smoother_pipeline(1 if device_controller == "pipelined" else 0)
         device_controller = True
     loop = _AdaptiveLoop(batch, adaptive_solver, sa_b[:, 0], dt0, vf=vector_field)
     if python_controller or loop.user_vf is not None:

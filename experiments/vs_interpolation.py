@@ -52,7 +52,7 @@ def checkpoint_runner(vf, inits, tspan, num_samples):
 
     def run(tol, save_at):
         asolver = ivpsolve.adaptive(solver, atol=tol, rtol=tol, control=ivpsolve.control_proportional_integral())
-        sol = ivpsolve.solve_adaptive_save_at(vf, init, save_at=save_at, dt0=0.01, adaptive_solver=asolver, device_controller=True)
+        sol = ivpsolve.solve_adaptive_save_at(vf, init, save_at=save_at, dt0=0.01, adaptive_solver=asolver, device_controller="pipelined")
         return sample_mean(sol, num_samples), len(save_at)
 
     return run

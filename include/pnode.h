@@ -223,13 +223,13 @@ int pnode_last_step_ms(pnode_batch* h, float* ms_out);
  * No environment variable influences the library: the choice is per handle, through this call only. */
 int pnode_set_generic_path(pnode_batch* h, int32_t enabled);
 /* Isotropic model, strategy_fixedpoint (src/odecheckpts/ivpsolvers.py:43), d <= 64, device-resident controller
- * (pnode_solve_adaptive_save_at_device): which of two kernels runs the attempts of a checkpoint interval. 1 = one workgroup per
- * trajectory, the filter and the controller on one wavefront and the backward transitions of the accepted steps on three others
- * (the chain of one trajectory is 1.6x shorter: single trajectories, tolerance sweeps, anything bound by its slowest member);
- * 2 = one wavefront per trajectory (highest throughput when the batch fills the device with equal work); 0 (default) = 1 when
- * every trajectory of the batch can be resident at once (#CUs x workgroups of that kernel per CU), else 2. Both kernels evaluate the same expressions in the
- * same order: the controller's decisions (accepted steps, step sizes) are identical bit for bit, the smoothed means agree to
- * rounding (1e-13 relative: multiply-adds of the backward transitions are contracted differently by the compiler). */
+ * (pnode_solve_adaptive_save_at_device): which of two kernels runs the attempts of a checkpoint interval. 0 (default) = one
+ * wavefront per trajectory (highest throughput when the batch fills the device with equal work); 1 = one workgroup per trajectory,
+ * the filter and the controller on one wavefront and the backward transitions of the accepted steps on three others (the chain of
+ * one trajectory is 1.6x shorter: single trajectories, tolerance sweeps, anything bound by its slowest member). Both kernels
+ * evaluate the same expressions in the same order: the controller's decisions (accepted steps, step sizes) are identical bit for
+ * bit, the smoothed means agree to rounding (1e-13 relative: multiply-adds of the backward transitions are contracted differently
+ * by the compiler) -- hence a per-handle choice of the caller, never one the library makes from the batch size. */
 int pnode_set_smoother_pipeline(pnode_batch* h, int32_t mode);
 /* Diagnostics of the one-launch LQ of the dense MFMA path (csrc/pnode_dense_lq4.hip): its wavefronts hand panels over through
  * flag words in LDS, and every wait is a bounded spin. A wait that runs into its bound is reported by the call that synchronises

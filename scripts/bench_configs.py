@@ -156,8 +156,7 @@ def main():
     run("C4 brusselator iso EKF0 nu=4 fixedpoint 200 ckpts", vf, [y0], 0.0, 10.0, model="isotropic", corr="ts0",
         strategy="fixedpoint", nu=4, atol=1e-8, rtol=1e-8, dt0=0.01, num_save=200, device_controller=True)
     vf, u0, (t0, t1), _ = ivps.rigid_body(time_span=(0.0, 50.0))
-    # (tolerance sweeps are bound by their slowest members: both kernels of the smoother's device controller; `True` would pick
-    # the one-wavefront kernel for 1024 > #CUs trajectories)
+    # (tolerance sweeps are bound by their slowest members: both kernels of the smoother's device controller)
     for dc in (True, "pipelined"):
         run("C3 rigid body nu=3 sweep", vf, [np.tile(u0[0], (B, 1))], t0, t1, model="isotropic", corr="ts0",
             strategy="fixedpoint", nu=3, atol=1e-3 * rt, rtol=rt, dt0=0.1, device_controller=dc)

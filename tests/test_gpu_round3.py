@@ -319,7 +319,7 @@ def test_device_resident_controller_of_the_dense_fixedpoint_smoother(hip_lib, N)
 def test_two_device_controllers_of_the_isotropic_fixedpoint_smoother_agree(hip_lib):
     """The device-resident controller of the isotropic fixed-point smoother (ivpsolvers.py:43) exists as two kernels: one wavefront
     per trajectory (iso_advance_kernel) and one workgroup per trajectory with the backward transitions of the accepted steps on
-    three wavefronts beside the filter (iso_advance_fp_kernel; chosen for batches of at most #CUs trajectories). Same expressions
+    three wavefronts beside the filter (iso_advance_fp_kernel; on request). Same expressions
     in the same order: identical decisions bit for bit -- also the host controller's -- and smoothed means equal to rounding (the
     multiply-adds of the transitions are contracted differently in the two kernels) (Brusselator N = 8, nu = 4 as in experiment 4, a tolerance sweep so that the trajectories differ)."""
     N, B = 8, 6
@@ -338,7 +338,7 @@ def test_two_device_controllers_of_the_isotropic_fixedpoint_smoother_agree(hip_l
         assert np.array_equal(dev.num_steps, host.num_steps)
         assert np.array_equal(dev.num_attempts, host.num_attempts)
         assert relmax(dev.u, host.u) < 1e-11
-    assert relmax(pipe.u, one.u) < 1e-12 and np.array_equal(auto.u, pipe.u)
+    assert relmax(pipe.u, one.u) < 1e-12 and np.array_equal(auto.u, one.u)  # (True = one wavefront per trajectory)
     with pytest.raises(ValueError):
         run("something else")
 
