@@ -11,7 +11,7 @@ store-every-step smoother would need, then that smoother itself while it fits) g
 with the reference's keys; the smoother runs while the steps fit the device-side store (ivpsolve.SMOOTHER_MAX_STEPS)
 and the reference's own 4000 MB gate.
 
-  python experiments/brusselator_checkpoints.py [--max-n 512] [--controller host|device] [--nosave] [--outdir DIR]
+  python experiments/brusselator_checkpoints.py [--max-n 512] [--controller host|device|pipelined] [--nosave] [--outdir DIR]
 """
 import argparse
 import os
@@ -32,7 +32,9 @@ from probdiffeq_hip.impl import impl  # noqa: E402
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--max-n", type=int, default=512)
-    ap.add_argument("--controller", default="device", choices=["host", "device"])
+    ap.add_argument("--controller", default="pipelined", choices=["host", "device", "pipelined"],
+                    help="pipelined: device-resident controller with the backward transitions beside the filter (d <= 64; the one-wavefront "
+                         "device controller beyond)")
     ap.add_argument("--nosave", action="store_true")
     ap.add_argument("--outdir", default=os.path.dirname(os.path.abspath(__file__)))
     args = ap.parse_args(argv)
@@ -75,7 +77,7 @@ def main(argv=None):
         # ---- checkpoint half (run.py:118-138)
         count0 = time.perf_counter()
         solution = ivpsolve.solve_adaptive_save_at(vf, init, save_at=save_at, dt0=0.01, adaptive_solver=adaptive_solver,
-                                                   device_controller=args.controller == "device")
+                                                   device_controller={"host": False, "device": True, "pipelined": "pipelined"}[args.controller])
         count1 = time.perf_counter() - count0
         steps = int(np.amax(solution.num_steps))
         results["N"].append(N)
