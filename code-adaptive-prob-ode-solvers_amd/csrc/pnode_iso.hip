@@ -225,6 +225,18 @@ struct IsoRegs {
   double sigma;
 };
 
+// (element by element: a struct assignment is a 250-byte memcpy that keeps both states in scratch memory from nu = 4 on)
+template <int N>
+__device__ __forceinline__ void iso_copy_regs(IsoRegs<N>& dst, const IsoRegs<N>& src) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    dst.m[i] = src.m[i];
+#pragma unroll
+    for (int j = 0; j < N; ++j) dst.R[i][j] = src.R[i][j];
+  }
+  dst.sigma = src.sigma;
+}
+
 template <int N>
 __device__ __forceinline__ void iso_load_regs(const IsoView& v, int b, int lane, int slot, IsoRegs<N>& s) {
   const int d = v.d;
@@ -282,16 +294,23 @@ __device__ __forceinline__ double iso_attempt_regs(const IsoView& v, const IwpCo
   VfCtx ctx{v.vf_id, d, k, v.prm ? v.prm + (v.prm_per_traj ? size_t(b) * v.P : 0) : nullptr,
             v.user_f ? v.user_f + size_t(b) * d : nullptr, v.user_J ? v.user_J + size_t(b) * d * k * d : nullptr};
   const double tnew = t + dt;
+  // (entry k of a register array by selection: a run-time index sends the whole array to scratch memory)
+  double mek = me[0], pk = p[0];
+#pragma unroll
+  for (int i = 1; i < N; ++i) {
+    mek = (i == k) ? me[i] : mek;
+    pk = (i == k) ? p[i] : pk;
+  }
   double z = 0.0, zz = 0.0;
   if (on) {
-    z = me[k] - vf_f(ctx, ybuf, lane, tnew);
+    z = mek - vf_f(ctx, ybuf, lane, tnew);
     zz += z * z;
   }
   zz = wave_sum(zz);
   __builtin_amdgcn_wave_barrier();  // (ybuf is rewritten by the next attempt)
 
   // --- calibration + error estimate
-  const double s1 = p[k] * K.qdiag_sqrt[k];
+  const double s1 = pk * K.qdiag_sqrt[k];
   const double sigma_hat = sqrt(zz) / (s1 * sqrt(double(d)));
   const double err = dt * sigma_hat * s1;
   const double sigma = v.dynamic ? sigma_hat : s.sigma;
@@ -305,7 +324,10 @@ __device__ __forceinline__ double iso_attempt_regs(const IsoView& v, const IwpCo
   double s2 = 0.0;
 #pragma unroll
   for (int c = 0; c < N; ++c) {
-    F[c] = Rm[c][k];
+    double f = Rm[c][0];
+#pragma unroll
+    for (int i = 1; i < N; ++i) f = (i == k) ? Rm[c][i] : f;
+    F[c] = f;
     s2 += F[c] * F[c];
   }
 #pragma unroll
@@ -399,7 +421,10 @@ __device__ __forceinline__ double iso_attempt(const IsoView& v, const IwpConst& 
   zz = team_sum<W>(zz, red, wteam);
 
   // --- calibration + error estimate (isotropic EKF0: S1 = s1^2, s1 = p_k * sqrt(Qbar_kk))
-  const double s1 = p[k] * K.qdiag_sqrt[k];
+  double pk = p[0];  // (entry k by selection: a run-time index sends the whole array to scratch memory)
+#pragma unroll
+  for (int i = 1; i < N; ++i) pk = (i == k) ? p[i] : pk;
+  const double s1 = pk * K.qdiag_sqrt[k];
   const double sigma_hat = sqrt(zz) / (s1 * sqrt(double(d)));
   const double err = dt * sigma_hat * s1;
   const double sigma_prev = v.sigma[size_t(arg.src) * sB + b];
@@ -446,7 +471,10 @@ __device__ __forceinline__ double iso_attempt(const IsoView& v, const IwpConst& 
   double s2 = 0.0;
 #pragma unroll
   for (int c = 0; c < N; ++c) {
-    F[c] = Rm[c][k];
+    double f = Rm[c][0];
+#pragma unroll
+    for (int i = 1; i < N; ++i) f = (i == k) ? Rm[c][i] : f;
+    F[c] = f;
     s2 += F[c] * F[c];
   }
 #pragma unroll
@@ -570,7 +598,7 @@ __global__ __launch_bounds__(256) void iso_advance_kernel(IsoView v, TrajCtl* __
         const int dst = c.s_pr;
         if (iso_after_attempt(c, cp, e, dt)) {
           iso_store_regs<N>(v, b, lane, dst, nw);
-          cur = nw;
+          iso_copy_regs<N>(cur, nw);
         }
         if (c.status == 2) break;
       }
@@ -696,7 +724,7 @@ __global__ __launch_bounds__(256) void iso_advance_fp_kernel(IsoView v, TrajCtl*
         ++acc;
         if (lane == 0) *pushedS = acc;
         iso_store_regs<N>(v, b, lane, dst, nw);
-        cur = nw;
+        iso_copy_regs<N>(cur, nw);
       }
       if (c.status == 2) break;
       if (__builtin_amdgcn_readfirstlane(*abortS)) {
