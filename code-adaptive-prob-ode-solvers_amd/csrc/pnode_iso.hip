@@ -218,53 +218,50 @@ __device__ __forceinline__ double team_sum(double v, double* red, int wteam) {
 // path: with the running backward transition beside two states the registers spill, and its attempt is bound by the three
 // Givens sweeps every lane computes, not by the round trips -- measured: no gain at nu = 3, 4, a loss of 6-9 % at nu = 5.)
 // ---------------------------------------------------------------------------------------------
+// (The state is three separate locals -- m[N]: my column of the mean (lanes < d), R[N][N]: factor, wave-uniform, sigma -- not a
+// struct: from nu = 4 on a struct of 31 doubles is not split into registers by the compiler and lives in scratch memory.)
 template <int N>
-struct IsoRegs {
-  double m[N];     // my column of the mean (lanes < d)
-  double R[N][N];  // factor, wave-uniform
-  double sigma;
-};
-
-// (element by element: a struct assignment is a 250-byte memcpy that keeps both states in scratch memory from nu = 4 on)
-template <int N>
-__device__ __forceinline__ void iso_copy_regs(IsoRegs<N>& dst, const IsoRegs<N>& src) {
+__device__ __forceinline__ void iso_copy_regs(double (&dm)[N], double (&dR)[N][N], double& dsig, const double (&sm)[N],
+                                              const double (&sR)[N][N], double ssig) {
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    dst.m[i] = src.m[i];
+    dm[i] = sm[i];
 #pragma unroll
-    for (int j = 0; j < N; ++j) dst.R[i][j] = src.R[i][j];
+    for (int j = 0; j < N; ++j) dR[i][j] = sR[i][j];
   }
-  dst.sigma = src.sigma;
+  dsig = ssig;
 }
 
 template <int N>
-__device__ __forceinline__ void iso_load_regs(const IsoView& v, int b, int lane, int slot, IsoRegs<N>& s) {
+__device__ __forceinline__ void iso_load_regs(const IsoView& v, int b, int lane, int slot, double (&m)[N], double (&R)[N][N], double& sigma) {
   const int d = v.d;
   const size_t sB = size_t(v.B);
   const double* msrc = v.mean + (size_t(slot) * sB + b) * N * d;
 #pragma unroll
-  for (int i = 0; i < N; ++i) s.m[i] = lane < d ? msrc[i * d + lane] : 0.0;
-  load_small<N>(v.fac + (size_t(slot) * sB + b) * N * N, s.R);
-  s.sigma = v.sigma[size_t(slot) * sB + b];
+  for (int i = 0; i < N; ++i) m[i] = lane < d ? msrc[i * d + lane] : 0.0;
+  load_small<N>(v.fac + (size_t(slot) * sB + b) * N * N, R);
+  sigma = v.sigma[size_t(slot) * sB + b];
 }
 
 template <int N>
-__device__ __forceinline__ void iso_store_regs(const IsoView& v, int b, int lane, int slot, const IsoRegs<N>& o) {
+__device__ __forceinline__ void iso_store_regs(const IsoView& v, int b, int lane, int slot, const double (&m)[N], const double (&R)[N][N],
+                                               double sigma) {
   const int d = v.d;
   const size_t sB = size_t(v.B);
   double* mdst = v.mean + (size_t(slot) * sB + b) * N * d;
   if (lane < d) {
 #pragma unroll
-    for (int i = 0; i < N; ++i) mdst[i * d + lane] = o.m[i];
+    for (int i = 0; i < N; ++i) mdst[i * d + lane] = m[i];
   }
-  store_small<N>(v.fac + (size_t(slot) * sB + b) * N * N, o.R, lane);
-  if (lane == 0) v.sigma[size_t(slot) * sB + b] = o.sigma;
+  store_small<N>(v.fac + (size_t(slot) * sB + b) * N * N, R, lane);
+  if (lane == 0) v.sigma[size_t(slot) * sB + b] = sigma;
 }
 
 // One attempted step from the state `s`. Returns the normalised error norm.
 template <int N>
 __device__ __forceinline__ double iso_attempt_regs(const IsoView& v, const IwpConst& K, int b, int lane, double dt, double t,
-                                                   const IsoRegs<N>& s, IsoRegs<N>& o, double atol, double rtol, double* ybuf,
+                                                   const double (&sm)[N], const double (&sR)[N][N], double ssigma, double (&om)[N],
+                                                   double (&oR)[N][N], double& osigma, double atol, double rtol, double* ybuf,
                                                    double (&me)[N]) {
   const int d = v.d, k = v.k;
   const bool on = lane < d;
@@ -275,7 +272,7 @@ __device__ __forceinline__ double iso_attempt_regs(const IsoView& v, const IwpCo
   {
     double mp[N];
 #pragma unroll
-    for (int i = 0; i < N; ++i) mp[i] = pinv[i] * s.m[i];
+    for (int i = 0; i < N; ++i) mp[i] = pinv[i] * sm[i];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       double acc = 0.0;
@@ -313,11 +310,11 @@ __device__ __forceinline__ double iso_attempt_regs(const IsoView& v, const IwpCo
   const double s1 = pk * K.qdiag_sqrt[k];
   const double sigma_hat = sqrt(zz) / (s1 * sqrt(double(d)));
   const double err = dt * sigma_hat * s1;
-  const double sigma = v.dynamic ? sigma_hat : s.sigma;
+  const double sigma = v.dynamic ? sigma_hat : ssigma;
 
   // --- n x n square-root time update
   double Rm[N][N], Gunused[N][N], RLunused[N][N];
-  iso_time_update<N, false>(K, s.R, p, pinv, sigma, Rm, Gunused, RLunused);
+  iso_time_update<N, false>(K, sR, p, pinv, sigma, Rm, Gunused, RLunused);
 
   // --- correction on z = 0
   double F[N], gain[N];
@@ -340,18 +337,18 @@ __device__ __forceinline__ double iso_attempt_regs(const IsoView& v, const IwpCo
 #pragma unroll
   for (int c = 0; c < N; ++c)
 #pragma unroll
-    for (int i = 0; i < N; ++i) o.R[c][i] = Rm[c][i] - F[c] * gain[i];
+    for (int i = 0; i < N; ++i) oR[c][i] = Rm[c][i] - F[c] * gain[i];
 
   // --- corrected mean + normalised error norm
   double acc2 = 0.0;
 #pragma unroll
-  for (int i = 0; i < N; ++i) o.m[i] = me[i] - gain[i] * z;
+  for (int i = 0; i < N; ++i) om[i] = me[i] - gain[i] * z;
   if (on) {
-    const double rel = err / (atol + rtol * fabs(o.m[0]));
+    const double rel = err / (atol + rtol * fabs(om[0]));
     acc2 += rel * rel;
   }
   acc2 = wave_sum(acc2);
-  o.sigma = sigma;
+  osigma = sigma;
   return sqrt(acc2 / double(d));
 }
 
@@ -368,11 +365,11 @@ __device__ __forceinline__ double iso_attempt(const IsoView& v, const IwpConst& 
   const int d = v.d, k = v.k;
   if constexpr (W == 1 && !FP) {
     if (d <= kWave) {  // one column per lane: the register form above
-      IsoRegs<N> s, o;
-      iso_load_regs<N>(v, b, lane, arg.src, s);
+      double sm[N], sR[N][N], ssig, om[N], oR[N][N], osig;
+      iso_load_regs<N>(v, b, lane, arg.src, sm, sR, ssig);
       double me[N];
-      const double e = iso_attempt_regs<N>(v, K, b, lane, arg.dt, arg.t, s, o, v.atol[b], v.rtol[b], ybuf, me);
-      iso_store_regs<N>(v, b, lane, arg.dst, o);
+      const double e = iso_attempt_regs<N>(v, K, b, lane, arg.dt, arg.t, sm, sR, ssig, om, oR, osig, v.atol[b], v.rtol[b], ybuf, me);
+      iso_store_regs<N>(v, b, lane, arg.dst, om, oR, osig);
       return e;
     }
   }
@@ -586,19 +583,19 @@ __global__ __launch_bounds__(256) void iso_advance_kernel(IsoView v, TrajCtl* __
       // INTERP_FROM are what the host reads after the launch), a rejected attempt leaves no trace
       const IwpConst& K = *Kc;
       const double atol = v.atol[b], rtol = v.rtol[b];
-      IsoRegs<N> cur;
-      iso_load_regs<N>(v, b, lane, c.s_sf, cur);
+      double cm[N], cR[N][N], csig;
+      iso_load_regs<N>(v, b, lane, c.s_sf, cm, cR, csig);
       while (c.t_sf + cp.numerical_zero < c.t_stop && iters < cp.max_iters) {
         double dt = c.dt;
         if (cp.clip) dt = fmin(dt, c.t_stop - c.t_sf);
-        IsoRegs<N> nw;
+        double nm[N], nR[N][N], nsig;
         double me[N];
-        const double e = iso_attempt_regs<N>(v, K, b, lane, dt, c.t_sf, cur, nw, atol, rtol, ybuf, me);
+        const double e = iso_attempt_regs<N>(v, K, b, lane, dt, c.t_sf, cm, cR, csig, nm, nR, nsig, atol, rtol, ybuf, me);
         ++iters;
         const int dst = c.s_pr;
         if (iso_after_attempt(c, cp, e, dt)) {
-          iso_store_regs<N>(v, b, lane, dst, nw);
-          iso_copy_regs<N>(cur, nw);
+          iso_store_regs<N>(v, b, lane, dst, nm, nR, nsig);
+          iso_copy_regs<N>(cm, cR, csig, nm, nR, nsig);
         }
         if (c.status == 2) break;
       }
@@ -689,14 +686,14 @@ __global__ __launch_bounds__(256) void iso_advance_fp_kernel(IsoView v, TrajCtl*
     int iters = 0, acc = 0;
     c.status = 0;
     const double atol = v.atol[b], rtol = v.rtol[b];
-    IsoRegs<N> cur;
-    iso_load_regs<N>(v, b, lane, c.s_sf, cur);
+    double cm[N], cR[N][N], csig;
+    iso_load_regs<N>(v, b, lane, c.s_sf, cm, cR, csig);
     while (c.t_sf + cp.numerical_zero < c.t_stop && iters < cp.max_iters) {
       double dt = c.dt;
       if (cp.clip) dt = fmin(dt, c.t_stop - c.t_sf);
-      IsoRegs<N> nw;
+      double nm[N], nR[N][N], nsig;
       double me[N];
-      const double e = iso_attempt_regs<N>(v, K, b, lane, dt, c.t_sf, cur, nw, atol, rtol, ybuf, me);
+      const double e = iso_attempt_regs<N>(v, K, b, lane, dt, c.t_sf, cm, cR, csig, nm, nR, nsig, atol, rtol, ybuf, me);
       ++iters;
       const int dst = c.s_pr;
       if (iso_after_attempt(c, cp, e, dt)) {
@@ -709,22 +706,22 @@ __global__ __launch_bounds__(256) void iso_advance_fp_kernel(IsoView v, TrajCtl*
           }
         }
         double* ent = ring + (acc % kFpRing) * EN;
-        store_small<N>(ent, cur.R, lane);
+        store_small<N>(ent, cR, lane);
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-          ent[N * N + i * kWave + lane] = cur.m[i];
+          ent[N * N + i * kWave + lane] = cm[i];
           ent[N * N + N * kWave + i * kWave + lane] = me[i];
         }
         if (lane == 0) {
           ent[EN - 4] = dt;
-          ent[EN - 3] = nw.sigma;
+          ent[EN - 3] = nsig;
           ent[EN - 2] = double(dst);
         }
         lds_done();
         ++acc;
         if (lane == 0) *pushedS = acc;
-        iso_store_regs<N>(v, b, lane, dst, nw);
-        iso_copy_regs<N>(cur, nw);
+        iso_store_regs<N>(v, b, lane, dst, nm, nR, nsig);
+        iso_copy_regs<N>(cm, cR, csig, nm, nR, nsig);
       }
       if (c.status == 2) break;
       if (__builtin_amdgcn_readfirstlane(*abortS)) {
