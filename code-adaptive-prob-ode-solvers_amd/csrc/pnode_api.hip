@@ -318,6 +318,8 @@ int pnode_create(const pnode_config* cfg, pnode_batch** out) {
       if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, cfg->device) != hipSuccess || ncu <= 0) ncu = 256;
       v.cus = ncu;
       v.fp_pipeline = 0;
+      v.fp_spin_limit = 0;
+      HIP_TRY_H(hipHostGetDevicePointer(reinterpret_cast<void**>(&v.fault), h->hFault, 0));
     }
     v.fixedpoint = cfg->strategy == PNODE_STRATEGY_FIXEDPOINT;
     v.dynamic = cfg->calibration == PNODE_CALIB_DYNAMIC;
@@ -477,6 +479,15 @@ int pnode_set_tolerances(pnode_batch* h, const double* atol, const double* rtol)
 // numerical result (the kernel drains and fills the outputs with NaN, which would otherwise read as a failed ODE).
 static int check_fault(pnode_batch* h) {
   if (!h->hFault || !h->hFault[0]) return PNODE_OK;
+  if (h->hFault[0] == 2) {  // pipelined controller of the isotropic fixed-point smoother (csrc/pnode_iso.hip)
+    static const char* wait[3] = {"ring full", "accepted step not handed over", "composition of the step before"};
+    const int w = h->hFault[3];
+    const std::string msg = "hand-shake of the pipelined smoother controller timed out (" + std::string(wait[w >= 0 && w < 3 ? w : 0]) +
+                            "), trajectory " + std::to_string(h->hFault[1]) + ": the state of the batch is undefined, call pnode_set_initial";
+    std::memset(h->hFault, 0, 4 * sizeof(int32_t));
+    h->initialised = false;
+    return fail(PNODE_EDEVICE, msg);
+  }
   static const char* kind[3] = {"panel / stored-strip flag", "LDS slot hand-over", "coefficient tables"};
   const int what = h->hFault[3] / 8, wave = h->hFault[3] % 8;
   const std::string msg = "LQ hand-shake timed out (" + std::string(kind[what < 3 && what >= 0 ? what : 0]) + "), trajectory " +
@@ -941,6 +952,8 @@ int pnode_solve_adaptive_save_at_device(pnode_batch* h, const double* save_at, i
         rc = fail(PNODE_EDEVICE, hipGetErrorString(e));
         break;
       }
+      rc = check_fault(h);
+      if (rc != PNODE_OK) break;
     }
     for (size_t b = 0; b < B; ++b) {
       const TrajCtl& c = hCtl[b];
@@ -1289,7 +1302,10 @@ int pnode_set_smoother_pipeline(pnode_batch* h, int32_t mode) {
 
 int pnode_debug_set_lq_spin_limit(pnode_batch* h, int32_t polls) {
   if (!h || polls < 0) return fail(PNODE_EINVAL, "bad argument");
-  if (!h->dense) return fail(PNODE_EINVAL, "the one-launch LQ belongs to the dense model");
+  if (!h->dense) {  // isotropic model: the waits of the pipelined smoother controller (pnode_set_smoother_pipeline)
+    h->iso.fp_spin_limit = polls;
+    return PNODE_OK;
+  }
   h->dn.lq_spin_limit = polls;
   return PNODE_OK;
 }

@@ -10,6 +10,8 @@ struct IsoView {
   int fixedpoint, dynamic, vf_id, P, prm_per_traj;
   int cus;          // compute units of the device
   int fp_pipeline;  // device-resident controller of the fixed-point smoother: 0 one wavefront per trajectory, 1 pipelined (workgroup per trajectory)
+  int fp_spin_limit;  // > 0: bound (in polls) of the waits of the pipelined kernel instead of its default (pnode_debug_set_lq_spin_limit)
+  int32_t* fault;   // pinned host words [4]: a hand-shake of the pipelined kernel that ran into its bound (fault[0] = 2, fault[1] = trajectory, fault[3] = wait)
   double* mean;   // [3][B][n][d]
   double* fac;    // [3][B][n][n]   Sigma = fac^T fac
   double* cG;     // [3][B][n][n]   running backward transition (fixedpoint)

@@ -680,6 +680,17 @@ __global__ __launch_bounds__(256) void iso_advance_fp_kernel(IsoView v, TrajCtl*
   }
   __syncthreads();  // the only workgroup barrier
   auto lds_done = [] { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+  const int spin_limit = v.fp_spin_limit > 0 ? v.fp_spin_limit : kFpSpin;
+  // A wait that runs into its bound is a synchronisation failure, not a result: reported through the handle's fault words (the
+  // call that synchronises returns PNODE_EDEVICE); every wait of the workgroup then falls through.
+  auto timed_out = [&](int which) {
+    if (lane == 0 && v.fault && !__builtin_amdgcn_readfirstlane(*abortS)) {
+      v.fault[1] = b;
+      v.fault[3] = which;
+      __atomic_store_n(v.fault, 2, __ATOMIC_RELEASE);
+    }
+    *abortS = 1;
+  };
 
   if (wv == 0) {
     // ---------------- filter + controller (iso_advance_kernel's loop), accepted steps handed to the ring
@@ -700,8 +711,8 @@ __global__ __launch_bounds__(256) void iso_advance_fp_kernel(IsoView v, TrajCtl*
         int n = 0;
         while (acc - __builtin_amdgcn_readfirstlane(*mergedS) >= kFpRing) {  // ring full: the smoother is behind
           __builtin_amdgcn_s_sleep(4);
-          if (++n > kFpSpin || __builtin_amdgcn_readfirstlane(*abortS)) {
-            *abortS = 1;
+          if (++n > spin_limit || __builtin_amdgcn_readfirstlane(*abortS)) {
+            if (n > spin_limit) timed_out(0);
             break;
           }
         }
@@ -747,8 +758,8 @@ __global__ __launch_bounds__(256) void iso_advance_fp_kernel(IsoView v, TrajCtl*
           break;
         }
         __builtin_amdgcn_s_sleep(4);
-        if (++n > kFpSpin || __builtin_amdgcn_readfirstlane(*abortS)) {
-          *abortS = 1;
+        if (++n > spin_limit || __builtin_amdgcn_readfirstlane(*abortS)) {
+          if (n > spin_limit) timed_out(1);
           have = false;
           break;
         }
@@ -782,8 +793,8 @@ __global__ __launch_bounds__(256) void iso_advance_fp_kernel(IsoView v, TrajCtl*
       bool ok = true;
       while (__builtin_amdgcn_readfirstlane(*mergedS) < a) {
         __builtin_amdgcn_s_sleep(2);
-        if (++n > kFpSpin || __builtin_amdgcn_readfirstlane(*abortS)) {
-          *abortS = 1;
+        if (++n > spin_limit || __builtin_amdgcn_readfirstlane(*abortS)) {
+          if (n > spin_limit) timed_out(2);
           ok = false;
           break;
         }

@@ -235,7 +235,9 @@ int pnode_set_smoother_pipeline(pnode_batch* h, int32_t mode);
  * flag words in LDS, and every wait is a bounded spin. A wait that runs into its bound is reported by the call that synchronises
  * with the device (pnode_attempt_step, pnode_advance_device, pnode_solve_*) as PNODE_EDEVICE with the trajectory and the awaited
  * value in pnode_last_error -- never as NaN results; the batch must then be re-initialised. polls > 0 replaces the default
- * bound (2^21 polls) so that tests can provoke the failure; 0 restores it. */
+ * bound (2^21 polls) so that tests can provoke the failure; 0 restores it. On a handle of the isotropic model the call sets the
+ * bound of the waits of the pipelined smoother controller (pnode_set_smoother_pipeline; ring and composition hand-shakes in LDS,
+ * default 2^22 polls), reported the same way. */
 int pnode_debug_set_lq_spin_limit(pnode_batch* h, int32_t polls);
 /* Enables HIP-event timing of attempt_step (all models). Dense model: also record HIP events between the kernels of a step (on the handle's stream) and
  * read the durations of the last attempt, ms_out[4] = {begin, lq_input, lq, correct}. */

@@ -368,3 +368,24 @@ def test_pipelined_smoother_controller_with_a_diverging_member(hip_lib):
     assert relmax(one.u[[0, 2]], pipe.u[[0, 2]]) < 1e-12
     assert np.array_equal(np.isnan(one.u), np.isnan(pipe.u))
     assert relmax(one.u[[0, 2]], host.u[[0, 2]]) < 1e-11
+
+
+def test_pipelined_smoother_handshake_timeout_is_a_device_error(hip_lib):
+    """The hand-shakes of the pipelined smoother controller (ring of accepted steps, composition chain, in LDS) are bounded spins
+    like the LQ's: with the bound set to one poll the smoother wavefronts give up before the filter wavefront has handed over its
+    first step, and the solve reports PNODE_EDEVICE -- never a quietly failed trajectory."""
+    N = 8
+    vf = V.brusselator(N)
+    y0 = np.stack([brusselator_y0(N, 0.3)])
+    tc = np.stack(tcoeffs(vf, [y0], 4), axis=1)
+    bt = _backend.Batch(batch=1, d=vf.d, nu=4, ode_order=1, model="isotropic", correction="ts0", strategy="fixedpoint",
+                        calibration="dynamic", vf_id=vf.vf_id, vf_params=vf.param_array(), num_checkpoints=3)
+    bt.set_initial(tc, np.zeros(1), np.ones(1))
+    bt.set_tolerances(1e-6, 1e-6)
+    bt.set_smoother_pipeline(1)
+    bt.debug_set_lq_spin_limit(1)
+    solver = ivpsolvers.solver_dynamic(ivpsolvers.strategy_fixedpoint(ivpsolvers.prior_ibm(4), ivpsolvers.correction_ts0()))
+    control = ivpsolve.adaptive(solver, atol=1e-6, rtol=1e-6).control
+    with pytest.raises(RuntimeError, match="pipelined smoother"):
+        bt.solve_adaptive_save_at(np.linspace(0.0, 1.0, 4), np.full(1, 0.01), control, 1e-12, device_controller=True)
+    bt.close()
