@@ -5,7 +5,8 @@
 // Same algorithm as pnode_dense.hip (generic path): row-Householder LQ time update, Gram-of-factor innovation,
 // projector-form measurement update. Lane j owns row j in the O(D^3) loops, so there are no cross-lane reductions
 // except the pivot-row norm. Also provides the device-resident controller loop (dense_small_advance_kernel).
-#include "pnode_device.hpp"
+#include "pnode_nxn.hpp"
+#include "pnode_vf.hpp"
 
 namespace pnode {
 
@@ -46,8 +47,147 @@ __device__ __forceinline__ void wsync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// ---------------------------------------------------------------------------------------------
+// d = 1 (a scalar ODE of order k <= 2: the reference's stiff Van der Pol run, vdp.py:61-66, BASELINE config 2): the dense model
+// is the isotropic one with one column, the EKF1 observation row is h = e_k - [J_0 .. J_{k-1}], and everything is n x n,
+// wave-uniform, in registers -- no LDS, no wavefront barrier (the general path below: about 40 barriers and 16 k cycles per
+// attempt at D = 5). Time update by Givens rotations (iso_time_update, pnode_nxn.hpp) on R = L^T; measurement update in projector
+// form; calibration from s1^2 = h (P Qbar P) h^T. The state factor is stored as L = R^T (lower triangular, positive diagonal).
+// ---------------------------------------------------------------------------------------------
+// state in: m, Rprev (= L^T), sigma_prev; out: mnew, Rnew, sigma_out; returns the normalised error norm
+template <int N>
+__device__ __forceinline__ double dense_d1_core(const DenseView& v, const IwpConst& K, int b, double dt, double t, const double (&m)[N],
+                                                const double (&Rprev)[N][N], double sigma_prev, double (&mnew)[N], double (&Rnew)[N][N],
+                                                double& sigma_out, double atol, double rtol) {
+  const int k = v.k;
+  double p[N], pinv[N];
+  preconditioner<N>(dt, K, p, pinv);
+  // m^- = P Abar P^-1 m
+  double me[N];
+  {
+    double mp[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) mp[i] = pinv[i] * m[i];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      double acc = 0.0;
+#pragma unroll
+      for (int kk = i; kk < N; ++kk) acc += K.a[i][kk] * mp[kk];
+      me[i] = p[i] * acc;
+    }
+  }
+  // residual and observation row at y = m^-[0 .. k-1]
+  double y[2] = {me[0], me[1]};
+  VfCtx ctx{v.vf_id, 1, k, v.prm ? v.prm + (v.prm_per_traj ? size_t(b) * v.P : 0) : nullptr,
+            v.user_f ? v.user_f + size_t(b) : nullptr, v.user_J ? v.user_J + size_t(b) * k : nullptr};
+  const double tnew = t + dt;
+  double mek = me[1];
+#pragma unroll
+  for (int i = 2; i < N; ++i) mek = (i == k) ? me[i] : mek;
+  const double z = mek - vf_f(ctx, y, 0, tnew);
+  double h[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) h[i] = (i == k) ? 1.0 : 0.0;
+  if (v.ts1) {
+    h[0] = -vf_jac(ctx, y, 0, 0, 0, tnew);
+    if (k > 1) h[1] = -vf_jac(ctx, y, 0, 1, 0, tnew);
+  }
+  // calibration + error estimate: s1^2 = h (P Qbar P) h^T = sum_c (sum_i chol(Qbar)^T[c][i] p_i h_i)^2
+  double s1sq = 0.0;
+#pragma unroll
+  for (int c = 0; c < N; ++c) {
+    double b0 = 0.0;
+#pragma unroll
+    for (int i = c; i < N; ++i) b0 += K.qsT[c][i] * (p[i] * h[i]);
+    s1sq += b0 * b0;
+  }
+  const double s1 = sqrt(s1sq);
+  const double sigma_hat = fabs(z) / s1;
+  const double err = dt * sigma_hat * s1;
+  const double sigma = v.dynamic ? sigma_hat : sigma_prev;
+  double Rm[N][N], Gu[N][N], RLu[N][N];
+  iso_time_update<N, false>(K, Rprev, p, pinv, sigma, Rm, Gu, RLu);
+  // measurement update on z = 0: F = h L^- = (Rm h)^T, gain = Sigma^- h^T / (F F^T), projector form
+  double F[N], gain[N];
+  double s2 = 0.0;
+#pragma unroll
+  for (int c = 0; c < N; ++c) {
+    double f = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) f += Rm[c][i] * h[i];
+    F[c] = f;
+    s2 += f * f;
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    double acc = 0.0;
+#pragma unroll
+    for (int c = 0; c < N; ++c) acc += Rm[c][i] * F[c];
+    gain[i] = acc / s2;
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) mnew[i] = me[i] - gain[i] * z;
+#pragma unroll
+  for (int c = 0; c < N; ++c)
+#pragma unroll
+    for (int i = 0; i < N; ++i) Rnew[c][i] = Rm[c][i] - F[c] * gain[i];
+  sigma_out = sigma;
+  const double rel = err / (atol + rtol * fabs(mnew[0]));
+  return fabs(rel);
+}
+
+template <int N>
+__device__ __forceinline__ void dense_d1_load(const DenseView& v, int b, int slot, double (&m)[N], double (&R)[N][N], double& sigma) {
+  const size_t sB = size_t(v.B);
+  const double* msrc = v.mean + (size_t(slot) * sB + b) * N;
+  const double* Lsrc = v.U + (size_t(slot) * sB + b) * N * N;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    m[i] = msrc[i];
+#pragma unroll
+    for (int c = 0; c < N; ++c) R[c][i] = Lsrc[i * N + c];  // R = L^T
+  }
+  sigma = v.sigma[size_t(slot) * sB + b];
+}
+
+template <int N>
+__device__ __forceinline__ void dense_d1_store(const DenseView& v, int b, int lane, int slot, const double (&m)[N], const double (&R)[N][N],
+                                               double sigma) {
+  const size_t sB = size_t(v.B);
+  double* mdst = v.mean + (size_t(slot) * sB + b) * N;
+  double* Ldst = v.U + (size_t(slot) * sB + b) * N * N;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    if (lane == i) mdst[i] = m[i];
+#pragma unroll
+    for (int c = 0; c < N; ++c)
+      if (lane == ((i * N + c) & 63)) Ldst[i * N + c] = R[c][i];
+  }
+  if (lane == 0) v.sigma[size_t(slot) * sB + b] = sigma;
+}
+
+template <int N>
+__device__ __forceinline__ double dense_d1_attempt(const DenseView& v, const IwpConst& K, int b, int lane, const StepArg& arg) {
+  double m[N], R[N][N], sig, mn[N], Rn[N][N], sign;
+  dense_d1_load<N>(v, b, arg.src, m, R, sig);
+  const double e = dense_d1_core<N>(v, K, b, arg.dt, arg.t, m, R, sig, mn, Rn, sign, v.atol[b], v.rtol[b]);
+  dense_d1_store<N>(v, b, lane, arg.dst, mn, Rn, sign);
+  return e;
+}
+
 // One attempted step by one wavefront; returns the normalised error norm (wave-uniform).
 __device__ double dense_small_attempt(const DenseView& v, const IwpConst& K, int b, int lane, const StepArg& arg, double* lds) {
+  if (v.d == 1 && v.k <= 2 && v.n >= 3) {  // scalar ODE: n x n in registers (above)
+    switch (v.n) {
+      case 3: return dense_d1_attempt<3>(v, K, b, lane, arg);
+      case 4: return dense_d1_attempt<4>(v, K, b, lane, arg);
+      case 5: return dense_d1_attempt<5>(v, K, b, lane, arg);
+      case 6: return dense_d1_attempt<6>(v, K, b, lane, arg);
+      case 7: return dense_d1_attempt<7>(v, K, b, lane, arg);
+      case 8: return dense_d1_attempt<8>(v, K, b, lane, arg);
+      default: break;
+    }
+  }
   const int d = v.d, k = v.k, n = v.n, D = v.D, kd = k * d, LD = D + 1, LS = d + 1;
   SmallLds s = small_carve(lds, D, d, k, n);
   const size_t sB = size_t(v.B);
@@ -256,6 +396,36 @@ __global__ __launch_bounds__(64) void dense_small_step_kernel(DenseView v, const
   if (threadIdx.x == 0) v.errnorm[b] = e;
 }
 
+// The controller's bookkeeping after an attempt with error norm e and step dt: returns whether the attempt is accepted; c.status = 2
+// ends the loop (same arithmetic as the host loop of pnode_solve_adaptive_save_at).
+__device__ __forceinline__ bool small_after_attempt(TrajCtl& c, const ControlParams& cp, double e, double dt) {
+  c.attempts += 1;
+  bool accept;
+  if (e != e) {
+    c.status = 2;
+    accept = true;
+  } else {
+    const double le = log(e);
+    const double raw = cp.safety * exp(cp.n2 * c.log_prev - (cp.n1 + cp.n2) * le);
+    const double factor = fmax(cp.factor_min, fmin(raw, cp.factor_max));
+    if (e <= 1.0) c.log_prev = le;
+    c.dt = factor * dt;
+    accept = !(e > 1.0);
+  }
+  if (accept) {
+    c.s_if = c.s_sf;
+    c.t_if = c.t_sf;
+    c.s_sf = c.s_pr;
+    c.t_sf += dt;
+    c.steps += 1;
+    int fr = 0;
+    while (fr == c.s_if || fr == c.s_sf) ++fr;
+    c.s_pr = fr;
+  }
+  if (c.status != 2 && !(isfinite(c.dt) && isfinite(c.t_sf) && c.dt > 0.0)) c.status = 2;
+  return accept;
+}
+
 // Device-resident controller (opt-in; same contract as iso_advance_kernel).
 __global__ __launch_bounds__(64) void dense_small_advance_kernel(DenseView v, TrajCtl* __restrict__ ctl,
                                                                  const IwpConst* __restrict__ Kc, ControlParams cp) {
@@ -274,34 +444,46 @@ __global__ __launch_bounds__(64) void dense_small_advance_kernel(DenseView v, Tr
     const double e = dense_small_attempt(v, *Kc, b, lane, arg, smem);
     __threadfence_block();
     ++iters;
-    c.attempts += 1;
-    bool accept;
-    if (e != e) {
-      c.status = 2;
-      accept = true;
-    } else {
-      const double le = log(e);
-      const double raw = cp.safety * exp(cp.n2 * c.log_prev - (cp.n1 + cp.n2) * le);
-      const double factor = fmax(cp.factor_min, fmin(raw, cp.factor_max));
-      if (e <= 1.0) c.log_prev = le;
-      c.dt = factor * dt;
-      accept = !(e > 1.0);
-    }
-    if (accept) {
-      c.s_if = c.s_sf;
-      c.t_if = c.t_sf;
-      c.s_sf = c.s_pr;
-      c.t_sf += dt;
-      c.steps += 1;
-      int fr = 0;
-      while (fr == c.s_if || fr == c.s_sf) ++fr;
-      c.s_pr = fr;
+    small_after_attempt(c, cp, e, dt);
+    if (c.status == 2) break;
+  }
+  if (c.status == 0) c.status = (c.t_sf + cp.numerical_zero >= c.t_stop) ? 1 : 3;
+  if (lane == 0) ctl[b] = c;
+}
+
+// The same for a scalar ODE (d = 1): the last accepted state stays in registers over the attempts of a launch, accepted states
+// are written to their slots (as iso_advance_kernel does for the isotropic filter).
+template <int N>
+__global__ __launch_bounds__(64) void dense_d1_advance_kernel(DenseView v, TrajCtl* __restrict__ ctl, const IwpConst* __restrict__ Kc,
+                                                              ControlParams cp) {
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x;
+  TrajCtl c = ctl[b];
+  if (c.status < 0) return;
+  const IwpConst& K = *Kc;
+  int iters = 0;
+  c.status = 0;
+  const double atol = v.atol[b], rtol = v.rtol[b];
+  double cm[N], cR[N][N], csig;
+  dense_d1_load<N>(v, b, c.s_sf, cm, cR, csig);
+  while (c.t_sf + cp.numerical_zero < c.t_stop && iters < cp.max_iters) {
+    double dt = c.dt;
+    if (cp.clip) dt = fmin(dt, c.t_stop - c.t_sf);
+    double nm[N], nR[N][N], nsig;
+    const double e = dense_d1_core<N>(v, K, b, dt, c.t_sf, cm, cR, csig, nm, nR, nsig, atol, rtol);
+    ++iters;
+    const int dst = c.s_pr;
+    if (small_after_attempt(c, cp, e, dt)) {
+      dense_d1_store<N>(v, b, lane, dst, nm, nR, nsig);
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        cm[i] = nm[i];
+#pragma unroll
+        for (int j = 0; j < N; ++j) cR[i][j] = nR[i][j];
+      }
+      csig = nsig;
     }
     if (c.status == 2) break;
-    if (!(isfinite(c.dt) && isfinite(c.t_sf) && c.dt > 0.0)) {
-      c.status = 2;
-      break;
-    }
   }
   if (c.status == 0) c.status = (c.t_sf + cp.numerical_zero >= c.t_stop) ? 1 : 3;
   if (lane == 0) ctl[b] = c;
@@ -316,6 +498,17 @@ void dense_small_launch_step(const DenseView& v, const StepArg* args, const IwpC
 }
 
 void dense_small_launch_advance(const DenseView& v, TrajCtl* ctl, const IwpConst* K, const ControlParams& cp, hipStream_t s) {
+  if (v.d == 1 && v.k <= 2) {  // scalar ODE: the register-resident loop
+    switch (v.n) {
+      case 3: hipLaunchKernelGGL(dense_d1_advance_kernel<3>, dim3(v.B), dim3(64), 0, s, v, ctl, K, cp); return;
+      case 4: hipLaunchKernelGGL(dense_d1_advance_kernel<4>, dim3(v.B), dim3(64), 0, s, v, ctl, K, cp); return;
+      case 5: hipLaunchKernelGGL(dense_d1_advance_kernel<5>, dim3(v.B), dim3(64), 0, s, v, ctl, K, cp); return;
+      case 6: hipLaunchKernelGGL(dense_d1_advance_kernel<6>, dim3(v.B), dim3(64), 0, s, v, ctl, K, cp); return;
+      case 7: hipLaunchKernelGGL(dense_d1_advance_kernel<7>, dim3(v.B), dim3(64), 0, s, v, ctl, K, cp); return;
+      case 8: hipLaunchKernelGGL(dense_d1_advance_kernel<8>, dim3(v.B), dim3(64), 0, s, v, ctl, K, cp); return;
+      default: break;
+    }
+  }
   hipLaunchKernelGGL(dense_small_advance_kernel, dim3(v.B), dim3(64), small_shm_bytes(v), s, v, ctl, K, cp);
 }
 
