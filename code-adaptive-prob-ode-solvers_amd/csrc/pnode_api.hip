@@ -1053,10 +1053,15 @@ int pnode_solve_fixed_grid(pnode_batch* h, const double* grid, int32_t G, int32_
   double* mean = mean_base(h);
   e = hipEventRecord(h->ev0, h->stream);
   if (e != hipSuccess) { cleanup(); return fail(PNODE_EDEVICE, hipGetErrorString(e)); }
-  for (int g = 0; g < G; ++g) {
-    if (g > 0) enqueue_step(h, dAll + size_t(g) * B);
-    hipLaunchKernelGGL(gather_u_kernel, dim3(unsigned(B)), dim3(64), 0, h->stream, mean, dAll + size_t(g) * B, dU, int(B),
-                       int(n), int(d), G, g);
+  if (h->dense && dense_d1_fixed_grid_supported(h->dn)) {  // scalar ODE: the whole grid in one launch (csrc/pnode_dense_small.hip)
+    h->stepped = true;
+    dense_d1_launch_fixed_grid(h->dn, dAll, h->dK, dU, G, h->stream);
+  } else {
+    for (int g = 0; g < G; ++g) {
+      if (g > 0) enqueue_step(h, dAll + size_t(g) * B);
+      hipLaunchKernelGGL(gather_u_kernel, dim3(unsigned(B)), dim3(64), 0, h->stream, mean, dAll + size_t(g) * B, dU, int(B),
+                         int(n), int(d), G, g);
+    }
   }
   e = hipEventRecord(h->ev1, h->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(u_out, dU, B * size_t(G) * d * sizeof(double), hipMemcpyDeviceToHost, h->stream);

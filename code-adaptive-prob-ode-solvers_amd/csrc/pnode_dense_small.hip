@@ -489,6 +489,55 @@ __global__ __launch_bounds__(64) void dense_d1_advance_kernel(DenseView v, TrajC
   if (lane == 0) ctl[b] = c;
 }
 
+// Fixed grid (pnode_solve_fixed_grid, the reference's solve_fixed_grid, vdp.py:88-105) for a scalar ODE: the whole replay in ONE
+// launch, a wavefront per trajectory walking over its G - 1 steps with the state in registers; u at every grid point goes to
+// `out` [B][G][1], the states of the last two steps to the slots the host's rotation assigns them (args[g * B + b]: dt, t, src, dst
+// of step g; entry 0 carries the initial slot). Launch per step: 10 us for 2 us of work (725 k steps of the reference's
+// "fixed, accurate" run: 7.2 s; its JAX CPU loop 6.5 s).
+template <int N>
+__global__ __launch_bounds__(64) void dense_d1_fixed_grid_kernel(DenseView v, const StepArg* __restrict__ args, const IwpConst* __restrict__ Kc,
+                                                                 double* __restrict__ out, int G) {
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x;
+  const IwpConst& K = *Kc;
+  const size_t B = size_t(v.B);
+  double cm[N], cR[N][N], csig;
+  dense_d1_load<N>(v, b, args[b].dst, cm, cR, csig);
+  if (lane == 0) out[size_t(b) * G] = cm[0];
+  const double atol = v.atol[b], rtol = v.rtol[b];
+#pragma unroll 1
+  for (int g = 1; g < G; ++g) {
+    const StepArg a = args[size_t(g) * B + b];
+    double nm[N], nR[N][N], nsig;
+    (void)dense_d1_core<N>(v, K, b, a.dt, a.t, cm, cR, csig, nm, nR, nsig, atol, rtol);
+    if (lane == 0) out[size_t(b) * G + g] = nm[0];
+    if (g >= G - 2) dense_d1_store<N>(v, b, lane, a.dst, nm, nR, nsig);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      cm[i] = nm[i];
+#pragma unroll
+      for (int j = 0; j < N; ++j) cR[i][j] = nR[i][j];
+    }
+    csig = nsig;
+  }
+}
+
+bool dense_d1_fixed_grid_supported(const DenseView& v) {
+  return v.d == 1 && v.k <= 2 && v.n >= 3 && v.n <= 8 && !v.fixedpoint && !v.force_generic;
+}
+
+void dense_d1_launch_fixed_grid(const DenseView& v, const StepArg* args, const IwpConst* K, double* out, int G, hipStream_t s) {
+  switch (v.n) {
+    case 3: hipLaunchKernelGGL(dense_d1_fixed_grid_kernel<3>, dim3(v.B), dim3(64), 0, s, v, args, K, out, G); break;
+    case 4: hipLaunchKernelGGL(dense_d1_fixed_grid_kernel<4>, dim3(v.B), dim3(64), 0, s, v, args, K, out, G); break;
+    case 5: hipLaunchKernelGGL(dense_d1_fixed_grid_kernel<5>, dim3(v.B), dim3(64), 0, s, v, args, K, out, G); break;
+    case 6: hipLaunchKernelGGL(dense_d1_fixed_grid_kernel<6>, dim3(v.B), dim3(64), 0, s, v, args, K, out, G); break;
+    case 7: hipLaunchKernelGGL(dense_d1_fixed_grid_kernel<7>, dim3(v.B), dim3(64), 0, s, v, args, K, out, G); break;
+    case 8: hipLaunchKernelGGL(dense_d1_fixed_grid_kernel<8>, dim3(v.B), dim3(64), 0, s, v, args, K, out, G); break;
+    default: break;
+  }
+}
+
 static size_t small_shm_bytes(const DenseView& v) { return small_lds_doubles(v.D, v.d, v.k, v.n) * sizeof(double); }
 
 bool dense_small_supported(const DenseView& v) { return v.D <= 32 && !v.fixedpoint; }
