@@ -389,3 +389,27 @@ def test_pipelined_smoother_handshake_timeout_is_a_device_error(hip_lib):
     with pytest.raises(RuntimeError, match="pipelined smoother"):
         bt.solve_adaptive_save_at(np.linspace(0.0, 1.0, 4), np.full(1, 0.01), control, 1e-12, device_controller=True)
     bt.close()
+
+
+def test_experiment_1_script_writes_the_references_files(hip_lib, golden, tmp_path):
+    """experiments/van_der_pol.py = the reference's experiment 1 (experiments/1_van_der_pol/vdp.py:45-132): the eight result files
+    with the reference's names, the baseline grid within the statistical band of the committed one (test_oracle_golden explains
+    why it is not the same grid), the replay of the adaptive grid and the fine equidistant grid finite, the coarse one diverged."""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("van_der_pol", os.path.join(root, "experiments", "van_der_pol.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    base, runs = mod.main(["--outdir", str(tmp_path)])
+    names = ["baseline_grid", "baseline_solution", "grid_adaptive", "grid_fixed_accurate", "grid_fixed_inaccurate", "runtime_adaptive",
+             "runtime_fixed_accurate", "runtime_fixed_inaccurate"]
+    for nme in names:
+        assert os.path.exists(os.path.join(str(tmp_path), f"vdp_{nme}.npy")), nme
+    ref = golden["vdp"]
+    assert abs(len(base.t) - len(ref["grid"])) <= 0.03 * len(ref["grid"]) and base.t[-1] == 6.3
+    assert np.max(np.abs(base.u[:25, 0] - ref["solution"][:25, 0])) < 1e-12
+    assert np.all(np.isfinite(runs["adaptive"][1].u)) and np.all(np.isfinite(runs["fixed_accurate"][1].u))
+    assert abs(runs["fixed_accurate"][1].u[-1, 0] - runs["adaptive"][1].u[-1, 0]) < 1e-2 * abs(runs["adaptive"][1].u[-1, 0])
+    assert np.load(os.path.join(str(tmp_path), "vdp_grid_fixed_accurate.npy")).shape[0] > 100 * len(base.t)
