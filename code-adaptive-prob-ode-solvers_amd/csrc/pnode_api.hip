@@ -844,6 +844,8 @@ int pnode_solve_adaptive_save_at_device(pnode_batch* h, const double* save_at, i
   // dense model beyond the fused one-wavefront kernel: multi-kernel form (controller kernel between the attempts), filter only
   const bool multi = h->dense && !(dense_small_supported(h->dn) && !h->dn.force_generic);
   if (h->cfg.vf_id == PNODE_VF_USER) return fail(PNODE_EINVAL, "the device-resident controller needs a built-in vector field");
+  if (!h->dense && !iso_advance_supported(h->iso))
+    return fail(PNODE_EINVAL, "device-resident controller: the isotropic fixed-point smoother with nu >= 5 is served for d <= 64; use the host controller");
   HIP_TRY(hipSetDevice(h->cfg.device));
   const size_t B = h->cfg.batch;
   const int K = num_save - 1;

@@ -1104,16 +1104,25 @@ static void launch_advance_n(const IsoView& v, TrajCtl* ctl, const IwpConst* K, 
   // higher throughput. Both take the same decisions bit for bit (the filter arithmetic is the same code); the smoothed means agree
   // to rounding (the compiler contracts the multiply-adds of the transitions differently in the two kernels) -- which is why the
   // choice is the caller's and never made from the batch size: a shard of a batch gives the bits of the unsharded solve.
-  const bool pipelined = v.fp_pipeline == 1;
+  // From nu = 5 on the one-wavefront kernel of the smoother (256 VGPRs + more than 100 spilled to AGPRs) ended in a memory
+  // access fault on the MI355X (iso_advance_kernel<6, true, 1>; a branch-free form of the Givens rotations moved the fault to
+  // nu = 4 instead of removing it: not understood, no such kernel is launched): the pipelined kernel serves those shapes.
+  const bool pipelined = v.fp_pipeline == 1 || N >= 6;
   if (v.fixedpoint && v.d <= kWave && pipelined) {
     hipLaunchKernelGGL((iso_advance_fp_kernel<N>), dim3(v.B), dim3(256), iso_fp_shm_doubles(N, v.k, v.d) * sizeof(double), s, v, ctl, K, cp);
     return;
   }
-  if (v.fixedpoint)
-    hipLaunchKernelGGL((iso_advance_kernel<N, true, 1>), dim3(blocks), dim3(256), iso_shm(v, 4), s, v, ctl, K, cp);
-  else
+  if (v.fixedpoint) {
+    if constexpr (N <= 5)  // (N >= 6, d > 64 is refused by iso_advance_supported: see above)
+      hipLaunchKernelGGL((iso_advance_kernel<N, true, 1>), dim3(blocks), dim3(256), iso_shm(v, 4), s, v, ctl, K, cp);
+  } else {
     hipLaunchKernelGGL((iso_advance_kernel<N, false, 1>), dim3(blocks), dim3(256), iso_shm(v, 4), s, v, ctl, K, cp);
+  }
 }
+// The device-resident controller exists for every shape except the fixed-point smoother with nu >= 5 beyond d = 64 (see
+// launch_advance_n): the caller falls back to the host controller there.
+bool iso_advance_supported(const IsoView& v) { return !(v.fixedpoint && v.n >= 6 && v.d > kWave); }
+
 void iso_launch_advance(const IsoView& v, TrajCtl* ctl, const IwpConst* K, const ControlParams& cp, hipStream_t s) {
 #define CALL(NN) launch_advance_n<NN>(v, ctl, K, cp, s)
   PNODE_DISPATCH_N(v.n, CALL)

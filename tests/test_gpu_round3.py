@@ -413,3 +413,36 @@ def test_experiment_1_script_writes_the_references_files(hip_lib, golden, tmp_pa
     assert np.all(np.isfinite(runs["adaptive"][1].u)) and np.all(np.isfinite(runs["fixed_accurate"][1].u))
     assert abs(runs["fixed_accurate"][1].u[-1, 0] - runs["adaptive"][1].u[-1, 0]) < 1e-2 * abs(runs["adaptive"][1].u[-1, 0])
     assert np.load(os.path.join(str(tmp_path), "vdp_grid_fixed_accurate.npy")).shape[0] > 100 * len(base.t)
+
+
+@pytest.mark.parametrize("case", ["rigid_nu2", "rigid_nu5", "pleiades2_nu3", "bruss32_nu3", "logistic_nu4"])
+def test_pipelined_smoother_controller_over_shapes(hip_lib, case):
+    """The pipelined device controller against the one-wavefront one and the host controller over the shapes the reference's
+    experiments use (d = 1, 3, 14, 64; ode order 1 and 2; nu = 2 .. 5): identical decisions, smoothed means equal to rounding."""
+    from odecheckpts import ivps
+
+    if case.startswith("rigid"):
+        vf, u0, (t0, t1), _ = ivps.rigid_body(time_span=(0.0, 5.0))
+        inits, nu = [np.tile(u0[0], (3, 1))], int(case[-1])
+    elif case.startswith("pleiades"):
+        vf, u0, (t0, t1) = ivps.pleiades_2nd()
+        t1, inits, nu = 0.5, [np.tile(u0[0], (3, 1)), np.tile(u0[1], (3, 1))], 3
+    elif case.startswith("bruss"):
+        vf = V.brusselator(32)
+        t0, t1, inits, nu = 0.0, 0.5, [np.stack([brusselator_y0(32, 0.4 * b) for b in range(3)])], 3
+    else:
+        vf = V.logistic(1.0, 1.0)
+        t0, t1, inits, nu = 0.0, 2.0, [np.array([[0.1], [0.2], [0.3]])], 4
+    impl.select("isotropic", ode_shape=(vf.d,))
+    solver = ivpsolvers.solver_dynamic(ivpsolvers.strategy_fixedpoint(ivpsolvers.prior_ibm(nu), ivpsolvers.correction_ts0(ode_order=vf.ode_order)))
+    tol = np.array([1e-3, 1e-5, 1e-7])
+    asolver = ivpsolve.adaptive(solver, atol=1e-3 * tol, rtol=tol)
+    init = solver.initial_condition(taylor.odejet_padded_scan(vf, inits, num=nu + 1 - vf.ode_order), 1.0)
+    save_at = np.linspace(t0, t1, 6)
+    run = lambda dc: ivpsolve.solve_adaptive_save_at(vf, init, save_at=save_at, dt0=0.01, adaptive_solver=asolver, device_controller=dc)
+    host, one, pipe = run(False), run("one-wavefront"), run("pipelined")
+    assert np.all(np.isfinite(host.u)) and host.num_steps[:, -1].min() >= 3
+    for dev in (one, pipe):
+        assert np.array_equal(dev.num_steps, host.num_steps) and np.array_equal(dev.num_attempts, host.num_attempts)
+        assert relmax(dev.u, host.u) < 1e-10
+    assert relmax(pipe.u, one.u) < 1e-12
