@@ -120,7 +120,12 @@ struct IwpConst {
   double qdiag_sqrt[kMaxN];  // sqrt(Qbar[i][i]) = || row i of chol(Qbar) ||
 };
 
+// Butterfly sum over the wavefront: every lane gets the SAME bits (each stage adds two rounded values, and the addition commutes).
+// The argument is made opaque first: with HIP's default -ffp-contract=fast a product in the caller (wave_sum(z * z)) would be
+// fused into the first stage, fma(z, z, partner's rounded z * z), and lanes i and i ^ 32 would get sums that differ in the last
+// bit (r04: found as an output scale that differed between the halves of a wavefront).
 __device__ __forceinline__ double wave_sum(double v) {
+  asm volatile("" : "+v"(v));
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
   return v;

@@ -2,15 +2,21 @@
 //
 // State per trajectory: mean (n x d) and ONE n x n factor R with Sigma = (R^T R) (x) I_d
 // (impl.select("isotropic"), /root/reference/src/odecheckpts/ivpsolvers.py:32-33). The n x n
-// algebra (IWP transition, Givens square-root time update, backward transition of the fixed-point
-// smoother, gain) is wave-uniform and lives in registers; the d-dimensional part (mean, residual,
-// error norm) is spread over the 64 lanes with wave-level reductions. The whole attempted step —
-// extrapolate, evaluate the vector field, calibrate, correct, normalise the error — is ONE kernel.
+// algebra (IWP transition, square-root time update, backward transition of the fixed-point
+// smoother, gain) is spread over the lanes of the wavefront, one column (or row) of a matrix per lane
+// (pnode_lanes.hpp); the d-dimensional part (mean, residual, error norm) has one ODE dimension per
+// lane, with wave-level reductions. The whole attempted step -- extrapolate, evaluate the vector
+// field, calibrate, correct, normalise the error -- is ONE kernel.
+//
+// Every lane stays enabled from the first to the last instruction of a kernel (r04): loops over the ODE
+// dimensions run a wave-uniform number of times on clamped indices, only stores are predicated. The row
+// broadcasts of pnode_lanes.hpp need it, and it removes the `lane < d` regions in whose join blocks the
+// compiler had placed register spills in front of the exec restore.
 //
 // Follows (arithmetic re-derived, see oracle/pn_oracle.py for the CPU restatement):
 //   correction_ts0 + strategy_filter/fixedpoint + solver[_dynamic]   ivpsolvers.py:37-50
 //   experiments/4_brusselator/run.py:51-61 (the configuration of the golden vectors)
-#include "pnode_nxn.hpp"
+#include "pnode_lanes.hpp"
 
 namespace pnode {
 
@@ -32,44 +38,94 @@ __device__ __forceinline__ double team_sum(double v, double* red, int wteam) {
   return t;
 }
 
+// Per-lane constants of a kernel: row l of Abar, column l of chol(Qbar)^T, (nu - l)!  (l = lane & 15)
+template <int N>
+struct LanePrior {
+  double arow[N], qcol[N], fact;
+};
+template <int N>
+__device__ __forceinline__ void load_lane_prior(const IwpConst* __restrict__ Kc, LanePrior<N>& P, int l) {
+  ln::load_prior<N>(Kc, P.arow, P.qcol, l);
+  const double f = Kc->fact[l < N ? l : N - 1];
+  P.fact = l < N ? f : 1.0;
+}
+
+// p_i = dt^(nu-i+1/2) / (nu-i)!,  pinv_i = 1/p_i   (probdiffeq preconditioner_diagonal): lane i forms its own pair (one
+// division each, all lanes side by side; the same sequence of multiplications as preconditioner() of pnode_common.hpp), the
+// uniform arrays come from row broadcasts. pl / pil: my lane's entries (0 beyond n).
+template <int N>
+__device__ __forceinline__ void preconditioner_lanes(double dt, double fact, int l, double (&p)[N], double (&pinv)[N], double& pl,
+                                                     double& pil) {
+  const double adt = fabs(dt);
+  double pw = sqrt(adt);  // dt^(0.5 + m), m = nu - l = N - 1 - l
+#pragma unroll
+  for (int s = 0; s < N - 1; ++s) pw = (N - 1 - l > s) ? pw * adt : pw;
+  const double mine = pw / fact, mine_inv = fact / pw;
+  ln::sfor<0, N>([&](auto ic) PNODE_LAMBDA_INLINE {
+    constexpr int i = decltype(ic)::value;
+    p[i] = ln::bcast<i>(mine);
+    pinv[i] = ln::bcast<i>(mine_inv);
+  });
+  pl = l < N ? mine : 0.0;
+  pil = l < N ? mine_inv : 0.0;
+}
+
+// Correction on z = 0 (isotropic EKF0): F = column k of Rm (row k of L^-), gain, projector-form update of the factor in place.
+// Returns the gain, one entry per lane (lane i: gain_i).
+template <int N>
+__device__ __forceinline__ double correct_factor(double (&Rm)[N], int k) {
+  double F[N];
+  double s2 = 0.0;
+#pragma unroll
+  for (int c = 0; c < N; ++c) {
+    F[c] = ln::lane_value(Rm[c], k);
+    s2 += F[c] * F[c];
+  }
+  double acc = 0.0;
+#pragma unroll
+  for (int c = 0; c < N; ++c) acc += Rm[c] * F[c];
+  const double gain = acc / s2;
+#pragma unroll
+  for (int c = 0; c < N; ++c) Rm[c] -= F[c] * gain;
+  return gain;
+}
 
 // ---------------------------------------------------------------------------------------------
-// Filter, d <= 64, one wavefront per trajectory: ONE column of the mean per lane, and the state of a trajectory fits the registers
+// Filter, d <= 64, one wavefront per trajectory: ONE ODE dimension per lane, and the state of a trajectory fits the registers
 // of its wavefront -- the attempted step as a function from registers to registers. iso_attempt (one launch per attempt, host
 // controller) wraps it in a load and a store; the device-resident controller (iso_advance_kernel) keeps the last accepted
 // state in registers over all the attempts of a launch and writes a state to its slot only when it is accepted: an attempt
-// then waits for no global memory at all (before: six dependent round trips per attempt, 33 k of its 45 k cycles at d = 64,
-// nu = 3). Same arithmetic, expression by expression, as the general path below. (The fixed-point smoother stays on the general
-// path: with the running backward transition beside two states the registers spill, and its attempt is bound by the three
-// Givens sweeps every lane computes, not by the round trips -- measured: no gain at nu = 3, 4, a loss of 6-9 % at nu = 5.)
+// then waits for no global memory at all.
+// State: m[N]: my ODE dimension of the mean (lanes < d, 0 beyond), R[N]: the factor, col-lane, sigma.
 // ---------------------------------------------------------------------------------------------
-// (The state is three separate locals -- m[N]: my column of the mean (lanes < d), R[N][N]: factor, wave-uniform, sigma -- not a
-// struct: from nu = 4 on a struct of 31 doubles is not split into registers by the compiler and lives in scratch memory.)
 template <int N>
-__device__ __forceinline__ void iso_copy_regs(double (&dm)[N], double (&dR)[N][N], double& dsig, const double (&sm)[N],
-                                              const double (&sR)[N][N], double ssig) {
+__device__ __forceinline__ void iso_copy_regs(double (&dm)[N], double (&dR)[N], double& dsig, const double (&sm)[N],
+                                              const double (&sR)[N], double ssig) {
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     dm[i] = sm[i];
-#pragma unroll
-    for (int j = 0; j < N; ++j) dR[i][j] = sR[i][j];
+    dR[i] = sR[i];
   }
   dsig = ssig;
 }
 
 template <int N>
-__device__ __forceinline__ void iso_load_regs(const IsoView& v, int b, int lane, int slot, double (&m)[N], double (&R)[N][N], double& sigma) {
+__device__ __forceinline__ void iso_load_regs(const IsoView& v, int b, int lane, int slot, double (&m)[N], double (&R)[N], double& sigma) {
   const int d = v.d;
   const size_t sB = size_t(v.B);
   const double* msrc = v.mean + (size_t(slot) * sB + b) * N * d;
+  const int jc = lane < d ? lane : d - 1;
 #pragma unroll
-  for (int i = 0; i < N; ++i) m[i] = lane < d ? msrc[i * d + lane] : 0.0;
-  load_small<N>(v.fac + (size_t(slot) * sB + b) * N * N, R);
+  for (int i = 0; i < N; ++i) {
+    const double x = msrc[i * d + jc];
+    m[i] = lane < d ? x : 0.0;
+  }
+  ln::load_cols<N>(v.fac + (size_t(slot) * sB + b) * N * N, R, lane & 15);
   sigma = v.sigma[size_t(slot) * sB + b];
 }
 
 template <int N>
-__device__ __forceinline__ void iso_store_regs(const IsoView& v, int b, int lane, int slot, const double (&m)[N], const double (&R)[N][N],
+__device__ __forceinline__ void iso_store_regs(const IsoView& v, int b, int lane, int slot, const double (&m)[N], const double (&R)[N],
                                                double sigma) {
   const int d = v.d;
   const size_t sB = size_t(v.B);
@@ -78,20 +134,20 @@ __device__ __forceinline__ void iso_store_regs(const IsoView& v, int b, int lane
 #pragma unroll
     for (int i = 0; i < N; ++i) mdst[i * d + lane] = m[i];
   }
-  store_small<N>(v.fac + (size_t(slot) * sB + b) * N * N, R, lane);
+  ln::store_cols<N>(v.fac + (size_t(slot) * sB + b) * N * N, R, lane);
   if (lane == 0) v.sigma[size_t(slot) * sB + b] = sigma;
 }
 
-// One attempted step from the state `s`. Returns the normalised error norm.
+// One attempted step from the state `s`. Returns the normalised error norm (a scalar the compiler knows to be uniform).
 template <int N>
-__device__ __forceinline__ double iso_attempt_regs(const IsoView& v, const IwpConst& K, int b, int lane, double dt, double t,
-                                                   const double (&sm)[N], const double (&sR)[N][N], double ssigma, double (&om)[N],
-                                                   double (&oR)[N][N], double& osigma, double atol, double rtol, double* ybuf,
-                                                   double (&me)[N]) {
-  const int d = v.d, k = v.k;
+__device__ __forceinline__ double iso_attempt_regs(const IsoView& v, const IwpConst& K, const LanePrior<N>& P, int b, int lane, double dt,
+                                                   double t, const double (&sm)[N], const double (&sR)[N], double ssigma, double (&om)[N],
+                                                   double (&oR)[N], double& osigma, double atol, double rtol, double* ybuf, double (&me)[N]) {
+  const int d = v.d, k = v.k, l = lane & 15;
   const bool on = lane < d;
-  double p[N], pinv[N];
-  preconditioner<N>(dt, K, p, pinv);
+  const int jc = on ? lane : d - 1;
+  double p[N], pinv[N], pl, pil;
+  preconditioner_lanes<N>(dt, P.fact, l, p, pinv, pl, pil);
 
   // --- mean extrapolation  m^- = P Abar P^{-1} m  (handed back: the fixed-point smoother's backward offset needs it)
   {
@@ -123,12 +179,9 @@ __device__ __forceinline__ double iso_attempt_regs(const IsoView& v, const IwpCo
     mek = (i == k) ? me[i] : mek;
     pk = (i == k) ? p[i] : pk;
   }
-  double z = 0.0, zz = 0.0;
-  if (on) {
-    z = mek - vf_f(ctx, ybuf, lane, tnew);
-    zz += z * z;
-  }
-  zz = wave_sum(zz);
+  const double zall = mek - vf_f(ctx, ybuf, jc, tnew);
+  const double z = on ? zall : 0.0;  // (lanes beyond d keep a zero column)
+  const double zz = ln::uniform(wave_sum(z * z));  // (uniform by construction; said to the compiler as well)
   __builtin_amdgcn_wave_barrier();  // (ybuf is rewritten by the next attempt)
 
   // --- calibration + error estimate
@@ -137,89 +190,70 @@ __device__ __forceinline__ double iso_attempt_regs(const IsoView& v, const IwpCo
   const double err = dt * sigma_hat * s1;
   const double sigma = v.dynamic ? sigma_hat : ssigma;
 
-  // --- n x n square-root time update
-  double Rm[N][N], Gunused[N][N], RLunused[N][N];
-  iso_time_update<N, false>(K, sR, p, pinv, sigma, Rm, Gunused, RLunused);
-
-  // --- correction on z = 0
-  double F[N], gain[N];
-  double s2 = 0.0;
-#pragma unroll
-  for (int c = 0; c < N; ++c) {
-    double f = Rm[c][0];
-#pragma unroll
-    for (int i = 1; i < N; ++i) f = (i == k) ? Rm[c][i] : f;
-    F[c] = f;
-    s2 += F[c] * F[c];
-  }
-#pragma unroll
-  for (int i = 0; i < N; ++i) {
-    double acc = 0.0;
-#pragma unroll
-    for (int c = 0; c < N; ++c) acc += Rm[c][i] * F[c];
-    gain[i] = acc / s2;
-  }
-#pragma unroll
-  for (int c = 0; c < N; ++c)
-#pragma unroll
-    for (int i = 0; i < N; ++i) oR[c][i] = Rm[c][i] - F[c] * gain[i];
+  // --- n x n square-root time update, correction on z = 0
+  double Gunused[N], RLunused[N];
+  ln::time_update<N, false>(P.arow, P.qcol, sR, pinv, pl, pil, sigma, l, oR, Gunused, RLunused);
+  const double gain = correct_factor<N>(oR, k);
 
   // --- corrected mean + normalised error norm
-  double acc2 = 0.0;
-#pragma unroll
-  for (int i = 0; i < N; ++i) om[i] = me[i] - gain[i] * z;
-  if (on) {
-    const double rel = err / (atol + rtol * fabs(om[0]));
-    acc2 += rel * rel;
-  }
-  acc2 = wave_sum(acc2);
+  ln::sfor<0, N>([&](auto ic) PNODE_LAMBDA_INLINE {
+    constexpr int i = decltype(ic)::value;
+    om[i] = me[i] - ln::bcast<i>(gain) * z;
+  });
+  const double rel = err / (atol + rtol * fabs(om[0]));
+  const double acc2 = wave_sum(on ? rel * rel : 0.0);
   osigma = sigma;
-  return sqrt(acc2 / double(d));
+  return ln::uniform(sqrt(acc2 / double(d)));
 }
 
 // One attempted step of trajectory b by a team of W wavefronts (W = 1: one wave per trajectory, four
 // trajectories per workgroup; W = 4: the whole 256-thread workgroup works on one trajectory, used for large d):
 // reads slot arg.src, writes slot arg.dst, returns the normalised error norm (team-uniform). `lane` is the
-// index inside the team (0 .. 64 W - 1); ybuf [k][d], zbuf [d], red [W] are the team's LDS scratch. The n x n
-// algebra is computed redundantly by every lane (no communication).
+// index inside the team (0 .. 64 W - 1); ybuf [k][d], zbuf [d], red [W] are the team's LDS scratch. Every wavefront of a team
+// carries the n x n algebra (identical copies); the first one writes it.
 template <int N, bool FP, int W>
-__device__ __forceinline__ double iso_attempt(const IsoView& v, const IwpConst& K, int b, int lane, const StepArg& arg,
-                                              double* ybuf, double* zbuf, double* red) {
+__device__ __forceinline__ double iso_attempt(const IsoView& v, const IwpConst& K, const LanePrior<N>& P, int b, int lane,
+                                              const StepArg& arg, double* ybuf, double* zbuf, double* red) {
   constexpr int kTeam = kWave * W;
-  const int wteam = lane >> 6;
+  const int wteam = lane >> 6, l = lane & 15;
   const int d = v.d, k = v.k;
   if constexpr (W == 1 && !FP) {
-    if (d <= kWave) {  // one column per lane: the register form above
-      double sm[N], sR[N][N], ssig, om[N], oR[N][N], osig;
+    if (d <= kWave) {  // one ODE dimension per lane: the register form above
+      double sm[N], sR[N], ssig, om[N], oR[N], osig;
       iso_load_regs<N>(v, b, lane, arg.src, sm, sR, ssig);
       double me[N];
-      const double e = iso_attempt_regs<N>(v, K, b, lane, arg.dt, arg.t, sm, sR, ssig, om, oR, osig, v.atol[b], v.rtol[b], ybuf, me);
+      const double e = iso_attempt_regs<N>(v, K, P, b, lane, arg.dt, arg.t, sm, sR, ssig, om, oR, osig, v.atol[b], v.rtol[b], ybuf, me);
       iso_store_regs<N>(v, b, lane, arg.dst, om, oR, osig);
       return e;
     }
   }
 
   const double dt = arg.dt;
-  double p[N], pinv[N];
-  preconditioner<N>(dt, K, p, pinv);
+  double p[N], pinv[N], pl, pil;
+  preconditioner_lanes<N>(dt, P.fact, l, p, pinv, pl, pil);
 
   const size_t sB = size_t(v.B);
   const double* msrc = v.mean + (size_t(arg.src) * sB + b) * N * d;
   double* mdst = v.mean + (size_t(arg.dst) * sB + b) * N * d;
 
   // --- pass A: mean extrapolation  m^- = P Abar P^{-1} m
-  for (int j = lane; j < d; j += kTeam) {
+  for (int j0 = 0; j0 < d; j0 += kTeam) {
+    const int j = j0 + lane;
+    const bool on = j < d;
+    const int jc = on ? j : d - 1;
     double mp[N];
 #pragma unroll
-    for (int i = 0; i < N; ++i) mp[i] = pinv[i] * msrc[i * d + j];
+    for (int i = 0; i < N; ++i) mp[i] = pinv[i] * msrc[i * d + jc];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       double acc = 0.0;
 #pragma unroll
       for (int kk = i; kk < N; ++kk) acc += K.a[i][kk] * mp[kk];
       const double e = p[i] * acc;
-      mdst[i * d + j] = e;
-      if (i < k) ybuf[i * d + j] = e;
+      if (on) {
+        mdst[i * d + j] = e;
+        if (i < k) ybuf[i * d + j] = e;
+      }
     }
   }
   if constexpr (W == 1) {
@@ -235,12 +269,17 @@ __device__ __forceinline__ double iso_attempt(const IsoView& v, const IwpConst& 
             v.user_f ? v.user_f + size_t(b) * d : nullptr, v.user_J ? v.user_J + size_t(b) * d * k * d : nullptr};
   const double tnew = arg.t + dt;
   double zz = 0.0;
-  for (int j = lane; j < d; j += kTeam) {
-    const double z = mdst[k * d + j] - vf_f(ctx, ybuf, j, tnew);
-    zbuf[j] = z;
-    zz += z * z;
+  for (int j0 = 0; j0 < d; j0 += kTeam) {
+    const int j = j0 + lane;
+    const bool on = j < d;
+    const int jc = on ? j : d - 1;
+    const double z = mdst[k * d + jc] - vf_f(ctx, ybuf, jc, tnew);
+    if (on) {
+      zbuf[j] = z;
+      zz += z * z;
+    }
   }
-  zz = team_sum<W>(zz, red, wteam);
+  zz = ln::uniform(team_sum<W>(zz, red, wteam));
 
   // --- calibration + error estimate (isotropic EKF0: S1 = s1^2, s1 = p_k * sqrt(Qbar_kk))
   double pk = p[0];  // (entry k by selection: a run-time index sends the whole array to scratch memory)
@@ -253,83 +292,72 @@ __device__ __forceinline__ double iso_attempt(const IsoView& v, const IwpConst& 
   const double sigma = v.dynamic ? sigma_hat : sigma_prev;
 
   // --- n x n square-root time update (+ backward transition for the fixed-point smoother)
-  double Rprev[N][N], Rm[N][N], G[N][N], RL[N][N];
-  load_small<N>(v.fac + (size_t(arg.src) * sB + b) * N * N, Rprev);
-  iso_time_update<N, FP>(K, Rprev, p, pinv, sigma, Rm, G, RL);
+  double Rprev[N], Rm[N], G[N], RL[N];
+  ln::load_cols<N>(v.fac + (size_t(arg.src) * sB + b) * N * N, Rprev, l);
+  ln::time_update<N, FP>(P.arow, P.qcol, Rprev, pinv, pl, pil, sigma, l, Rm, G, RL);
 
   if constexpr (FP) {
     // xi = m - G m^-, merged with the running backward transition of the source slot
-    double G0[N][N], RL0[N][N];
-    load_small<N>(v.cG + (size_t(arg.src) * sB + b) * N * N, G0);
-    load_small<N>(v.cLam + (size_t(arg.src) * sB + b) * N * N, RL0);
+    double G0[N], RL0[N];
+    ln::load_rows<N>(v.cG + (size_t(arg.src) * sB + b) * N * N, G0, l);
+    ln::load_cols<N>(v.cLam + (size_t(arg.src) * sB + b) * N * N, RL0, l);
     const double* xi0 = v.cxi + (size_t(arg.src) * sB + b) * N * d;
     double* xid = v.cxi + (size_t(arg.dst) * sB + b) * N * d;
-    for (int j = lane; j < d; j += kTeam) {
-      double xi[N], me[N];
-#pragma unroll
-      for (int i = 0; i < N; ++i) me[i] = mdst[i * d + j];
+    for (int j0 = 0; j0 < d; j0 += kTeam) {
+      const int j = j0 + lane;
+      const bool on = j < d;
+      const int jc = on ? j : d - 1;
+      double xi[N], me[N], acc[N];
 #pragma unroll
       for (int i = 0; i < N; ++i) {
-        double acc = msrc[i * d + j];
-#pragma unroll
-        for (int kk = 0; kk < N; ++kk) acc -= G[i][kk] * me[kk];
-        xi[i] = acc;
+        me[i] = mdst[i * d + jc];
+        xi[i] = msrc[i * d + jc];
+        acc[i] = xi0[i * d + jc];
       }
+      ln::opaque(G);
+      ln::opaque(G0);
+      ln::matvec_rows<N, -1>(G, me, xi);
+      ln::matvec_rows<N, +1>(G0, xi, acc);
+      if (on) {
 #pragma unroll
-      for (int i = 0; i < N; ++i) {
-        double acc = xi0[i * d + j];
-#pragma unroll
-        for (int kk = 0; kk < N; ++kk) acc += G0[i][kk] * xi[kk];
-        xid[i * d + j] = acc;
+        for (int i = 0; i < N; ++i) xid[i * d + j] = acc[i];
       }
     }
-    iso_merge_small<N>(G0, RL0, G, RL);
-    store_small<N>(v.cG + (size_t(arg.dst) * sB + b) * N * N, G, lane);
-    store_small<N>(v.cLam + (size_t(arg.dst) * sB + b) * N * N, RL, lane);
+    ln::merge<N>(G0, RL0, G, RL, l);
+    ln::store_rows<N>(v.cG + (size_t(arg.dst) * sB + b) * N * N, G, lane);
+    ln::store_cols<N>(v.cLam + (size_t(arg.dst) * sB + b) * N * N, RL, lane);
   }
 
   // --- correction on z = 0: F = row k of L^- = column k of Rm; gain; projector-form update
-  double F[N], gain[N];
-  double s2 = 0.0;
-#pragma unroll
-  for (int c = 0; c < N; ++c) {
-    double f = Rm[c][0];
-#pragma unroll
-    for (int i = 1; i < N; ++i) f = (i == k) ? Rm[c][i] : f;
-    F[c] = f;
-    s2 += F[c] * F[c];
-  }
-#pragma unroll
-  for (int i = 0; i < N; ++i) {
-    double acc = 0.0;
-#pragma unroll
-    for (int c = 0; c < N; ++c) acc += Rm[c][i] * F[c];
-    gain[i] = acc / s2;
-  }
-#pragma unroll
-  for (int c = 0; c < N; ++c)
-#pragma unroll
-    for (int i = 0; i < N; ++i) Rm[c][i] -= F[c] * gain[i];
-  store_small<N>(v.fac + (size_t(arg.dst) * sB + b) * N * N, Rm, lane);
+  const double gain = correct_factor<N>(Rm, k);
+  ln::store_cols<N>(v.fac + (size_t(arg.dst) * sB + b) * N * N, Rm, lane);
+  double gu[N];
+  ln::sfor<0, N>([&](auto ic) PNODE_LAMBDA_INLINE {
+    constexpr int i = decltype(ic)::value;
+    gu[i] = ln::bcast<i>(gain);
+  });
 
   // --- pass C: corrected mean + normalised error norm
   const double atol = v.atol[b], rtol = v.rtol[b];
   double acc2 = 0.0;
-  for (int j = lane; j < d; j += kTeam) {
-    const double z = zbuf[j];
+  for (int j0 = 0; j0 < d; j0 += kTeam) {
+    const int j = j0 + lane;
+    const bool on = j < d;
+    const int jc = on ? j : d - 1;
+    const double z = zbuf[jc];
     double u0 = 0.0;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-      const double mnew = mdst[i * d + j] - gain[i] * z;
-      mdst[i * d + j] = mnew;
+      const double mnew = mdst[i * d + jc] - gu[i] * z;
+      if (on) mdst[i * d + j] = mnew;
       if (i == 0) u0 = mnew;
     }
     const double rel = err / (atol + rtol * fabs(u0));
-    acc2 += rel * rel;
+    acc2 += on ? rel * rel : 0.0;
   }
   acc2 = team_sum<W>(acc2, red, wteam);
   if (lane == 0) v.sigma[size_t(arg.dst) * sB + b] = sigma;
-  return sqrt(acc2 / double(d));
+  return ln::uniform(sqrt(acc2 / double(d)));
 }
 
 template <int N, bool FP, int W>
@@ -346,14 +374,17 @@ __global__ __launch_bounds__(256) void iso_step_kernel(IsoView v, const StepArg*
   double* ybuf = smem + size_t(team) * ((size_t(v.k) + 1) * v.d + 4);  // [k][d] staged state for the vector field
   double* zbuf = ybuf + size_t(v.k) * v.d;                            // [d] residual
   double* red = zbuf + v.d;                                           // [W]
-  const double e = iso_attempt<N, FP, W>(v, *Kc, b, lane, arg, ybuf, zbuf, red);
+  LanePrior<N> P;
+  load_lane_prior<N>(Kc, P, lane & 15);
+  const double e = iso_attempt<N, FP, W>(v, *Kc, P, b, lane, arg, ybuf, zbuf, red);
   if (lane == 0) v.errnorm[b] = e;
 }
 
 // Device-resident controller (opt-in): every wavefront runs the accept/reject loop and the PI
 // step-size law for ITS trajectory until the next save_at point is reached (or an iteration budget is spent), so
 // the host synchronises once per checkpoint interval instead of once per attempted step. Same arithmetic as the
-// host controller in pnode_solve_adaptive_save_at.
+// host controller in pnode_solve_adaptive_save_at. The controller's state is wave-uniform and known to the compiler as such
+// (scalar loads, the error norm through ln::uniform): its branches are scalar branches, no lane is ever disabled by them.
 // The controller's bookkeeping after an attempt with error norm e and step dt (both loops of iso_advance_kernel): returns
 // whether the state of the attempt is accepted; c.status = 2 ends the loop.
 __device__ __forceinline__ bool iso_after_attempt(TrajCtl& c, const ControlParams& cp, double e, double dt) {
@@ -363,18 +394,18 @@ __device__ __forceinline__ bool iso_after_attempt(TrajCtl& c, const ControlParam
     c.status = 2;  // NaN error estimate: stop (the reference accepts the NaN state and fails later)
     accept = true;
   } else {
-    const double le = log(e);
+    const double le = ln::uniform(log(e));
     const double raw = cp.safety * exp(cp.n2 * c.log_prev - (cp.n1 + cp.n2) * le);
     const double factor = fmax(cp.factor_min, fmin(raw, cp.factor_max));
     if (e <= 1.0) c.log_prev = le;
-    c.dt = factor * dt;
+    c.dt = ln::uniform(factor * dt);
     accept = !(e > 1.0);
   }
   if (accept) {
     c.s_if = c.s_sf;
     c.t_if = c.t_sf;
     c.s_sf = c.s_pr;
-    c.t_sf += dt;
+    c.t_sf = ln::uniform(c.t_sf + dt);
     c.steps += 1;
     int fr = 0;
     while (fr == c.s_if || fr == c.s_sf) ++fr;
@@ -398,6 +429,8 @@ __global__ __launch_bounds__(256) void iso_advance_kernel(IsoView v, TrajCtl* __
   double* ybuf = smem + size_t(team) * ((size_t(v.k) + 1) * v.d + 4);
   double* zbuf = ybuf + size_t(v.k) * v.d;
   double* red = zbuf + v.d;
+  LanePrior<N> P;
+  load_lane_prior<N>(Kc, P, lane & 15);
   int iters = 0;
   c.status = 0;
   bool in_registers = false;
@@ -408,14 +441,14 @@ __global__ __launch_bounds__(256) void iso_advance_kernel(IsoView v, TrajCtl* __
       // INTERP_FROM are what the host reads after the launch), a rejected attempt leaves no trace
       const IwpConst& K = *Kc;
       const double atol = v.atol[b], rtol = v.rtol[b];
-      double cm[N], cR[N][N], csig;
+      double cm[N], cR[N], csig;
       iso_load_regs<N>(v, b, lane, c.s_sf, cm, cR, csig);
       while (c.t_sf + cp.numerical_zero < c.t_stop && iters < cp.max_iters) {
         double dt = c.dt;
         if (cp.clip) dt = fmin(dt, c.t_stop - c.t_sf);
-        double nm[N], nR[N][N], nsig;
+        double nm[N], nR[N], nsig;
         double me[N];
-        const double e = iso_attempt_regs<N>(v, K, b, lane, dt, c.t_sf, cm, cR, csig, nm, nR, nsig, atol, rtol, ybuf, me);
+        const double e = iso_attempt_regs<N>(v, K, P, b, lane, dt, c.t_sf, cm, cR, csig, nm, nR, nsig, atol, rtol, ybuf, me);
         ++iters;
         const int dst = c.s_pr;
         if (iso_after_attempt(c, cp, e, dt)) {
@@ -431,7 +464,7 @@ __global__ __launch_bounds__(256) void iso_advance_kernel(IsoView v, TrajCtl* __
       if (cp.clip) dt = fmin(dt, c.t_stop - c.t_sf);
       StepArg arg;
       arg.dt = dt; arg.t = c.t_sf; arg.src = c.s_sf; arg.dst = c.s_pr; arg.active = 1; arg.pad = 0;
-      const double e = iso_attempt<N, FP, W>(v, *Kc, b, lane, arg, ybuf, zbuf, red);
+      const double e = iso_attempt<N, FP, W>(v, *Kc, P, b, lane, arg, ybuf, zbuf, red);
       if constexpr (W > 1) __syncthreads();
       __threadfence_block();  // the slot written by this attempt is read by the next one (other lanes of the team)
       ++iters;
@@ -446,10 +479,10 @@ __global__ __launch_bounds__(256) void iso_advance_kernel(IsoView v, TrajCtl* __
 // ---------------------------------------------------------------------------------------------
 // Device-resident controller of the FIXED-POINT SMOOTHER, d <= 64: one workgroup of four wavefronts per trajectory.
 // An attempt of the smoother is the filter's attempt plus the backward transition of the step and its composition with the
-// running transition (ivpsolvers.py:43) -- four fifths of the instructions, none of which the controller's decision needs.
-// Wavefront 0 runs the filter and the controller exactly like iso_advance_kernel (state in registers, 5 us per attempt); every
+// running transition (ivpsolvers.py:43), none of which the controller's decision needs.
+// Wavefront 0 runs the filter and the controller exactly like iso_advance_kernel (state in registers); every
 // ACCEPTED step goes into a ring in LDS (previous factor and mean, extrapolated mean, dt, sigma, destination slot). The
-// wavefronts 1..3 take the steps a = w - 1, w + 2, .. : the transition of a step (iso_time_update<N, true>) depends on that
+// wavefronts 1..3 take the steps a = w - 1, w + 2, .. : the transition of a step (ln::time_update<N, true>) depends on that
 // step alone, so three are in flight; the compositions are chained through the running transition in LDS (mergedS), which is
 // written to the step's slot as it goes: at the end of the launch STEP_FROM and INTERP_FROM hold theirs, as the host-driven
 // path leaves them. Same arithmetic, expression by expression, as iso_attempt<N, true, 1>. Every wait is a bounded spin.
@@ -469,7 +502,7 @@ __global__ __launch_bounds__(256) void iso_advance_fp_kernel(IsoView v, TrajCtl*
                                                              ControlParams cp) {
   extern __shared__ double smem[];
   constexpr int EN = iso_fp_entry_doubles<N>();
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63, l = lane & 15;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x;
   if (b >= v.B) return;
@@ -500,10 +533,16 @@ __global__ __launch_bounds__(256) void iso_advance_fp_kernel(IsoView v, TrajCtl*
       runL[e] = v.cLam[(size_t(c.s_sf) * sB + b) * N * N + e];
     }
     const double* xi0 = v.cxi + (size_t(c.s_sf) * sB + b) * N * d;
+    const int jc = lane < d ? lane : d - 1;
 #pragma unroll
-    for (int i = 0; i < N; ++i) runX[i * kWave + lane] = lane < d ? xi0[i * d + lane] : 0.0;
+    for (int i = 0; i < N; ++i) {
+      const double x = xi0[i * d + jc];
+      runX[i * kWave + lane] = lane < d ? x : 0.0;
+    }
   }
   __syncthreads();  // the only workgroup barrier
+  LanePrior<N> P;
+  load_lane_prior<N>(Kc, P, l);
   auto lds_done = [] { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
   const int spin_limit = v.fp_spin_limit > 0 ? v.fp_spin_limit : kFpSpin;
   // A wait that runs into its bound is a synchronisation failure, not a result: reported through the handle's fault words (the
@@ -522,14 +561,14 @@ __global__ __launch_bounds__(256) void iso_advance_fp_kernel(IsoView v, TrajCtl*
     int iters = 0, acc = 0;
     c.status = 0;
     const double atol = v.atol[b], rtol = v.rtol[b];
-    double cm[N], cR[N][N], csig;
+    double cm[N], cR[N], csig;
     iso_load_regs<N>(v, b, lane, c.s_sf, cm, cR, csig);
     while (c.t_sf + cp.numerical_zero < c.t_stop && iters < cp.max_iters) {
       double dt = c.dt;
       if (cp.clip) dt = fmin(dt, c.t_stop - c.t_sf);
-      double nm[N], nR[N][N], nsig;
+      double nm[N], nR[N], nsig;
       double me[N];
-      const double e = iso_attempt_regs<N>(v, K, b, lane, dt, c.t_sf, cm, cR, csig, nm, nR, nsig, atol, rtol, ybuf, me);
+      const double e = iso_attempt_regs<N>(v, K, P, b, lane, dt, c.t_sf, cm, cR, csig, nm, nR, nsig, atol, rtol, ybuf, me);
       ++iters;
       const int dst = c.s_pr;
       if (iso_after_attempt(c, cp, e, dt)) {
@@ -542,7 +581,7 @@ __global__ __launch_bounds__(256) void iso_advance_fp_kernel(IsoView v, TrajCtl*
           }
         }
         double* ent = ring + (acc % kFpRing) * EN;
-        store_small<N>(ent, cR, lane);
+        ln::store_cols<N>(ent, cR, lane);
 #pragma unroll
         for (int i = 0; i < N; ++i) {
           ent[N * N + i * kWave + lane] = cm[i];
@@ -592,27 +631,23 @@ __global__ __launch_bounds__(256) void iso_advance_fp_kernel(IsoView v, TrajCtl*
       if (!have) break;
       asm volatile("" ::: "memory");
       const double* ent = ring + (a % kFpRing) * EN;
-      double Rprev[N][N], Rm[N][N], G[N][N], RL[N][N];
-      load_small<N>(ent, Rprev);
-      const double dt = ent[EN - 4], sigma = ent[EN - 3];
-      const int dst = int(ent[EN - 2]);
+      double Rprev[N], Rm[N], G[N], RL[N];
+      ln::load_cols<N>(ent, Rprev, l);
+      const double dt = ln::uniform(ent[EN - 4]), sigma = ln::uniform(ent[EN - 3]);
+      const int dst = __builtin_amdgcn_readfirstlane(int(ent[EN - 2]));
       double mprev[N], me[N];
 #pragma unroll
       for (int i = 0; i < N; ++i) {
         mprev[i] = ent[N * N + i * kWave + lane];
         me[i] = ent[N * N + N * kWave + i * kWave + lane];
       }
-      double p[N], pinv[N];
-      preconditioner<N>(dt, K, p, pinv);
-      iso_time_update<N, true>(K, Rprev, p, pinv, sigma, Rm, G, RL);
+      double p[N], pinv[N], pl, pil;
+      preconditioner_lanes<N>(dt, P.fact, l, p, pinv, pl, pil);
+      ln::time_update<N, true>(P.arow, P.qcol, Rprev, pinv, pl, pil, sigma, l, Rm, G, RL);
       double xi[N];
 #pragma unroll
-      for (int i = 0; i < N; ++i) {
-        double s = mprev[i];
-#pragma unroll
-        for (int kk = 0; kk < N; ++kk) s -= G[i][kk] * me[kk];
-        xi[i] = s;
-      }
+      for (int i = 0; i < N; ++i) xi[i] = mprev[i];
+      ln::matvec_rows<N, -1>(G, me, xi);
       // composition with the running transition: in the order of the steps
       n = 0;
       bool ok = true;
@@ -626,21 +661,17 @@ __global__ __launch_bounds__(256) void iso_advance_fp_kernel(IsoView v, TrajCtl*
       }
       if (!ok) break;
       asm volatile("" ::: "memory");
-      double G0[N][N], RL0[N][N];
-      load_small<N>(runG, G0);
-      load_small<N>(runL, RL0);
+      double G0[N], RL0[N];
+      ln::load_rows<N>(runG, G0, l);
+      ln::load_cols<N>(runL, RL0, l);
       double xn[N];
 #pragma unroll
-      for (int i = 0; i < N; ++i) {
-        double s = runX[i * kWave + lane];
-#pragma unroll
-        for (int kk = 0; kk < N; ++kk) s += G0[i][kk] * xi[kk];
-        xn[i] = s;
-      }
-      iso_merge_small<N>(G0, RL0, G, RL);
+      for (int i = 0; i < N; ++i) xn[i] = runX[i * kWave + lane];
+      ln::matvec_rows<N, +1>(G0, xi, xn);
+      ln::merge<N>(G0, RL0, G, RL, l);
       lds_done();  // (my reads of the running transition are complete before it is overwritten)
-      store_small<N>(runG, G, lane);
-      store_small<N>(runL, RL, lane);
+      ln::store_rows<N>(runG, G, lane);
+      ln::store_cols<N>(runL, RL, lane);
 #pragma unroll
       for (int i = 0; i < N; ++i) runX[i * kWave + lane] = xn[i];
       double* xid = v.cxi + (size_t(dst) * sB + b) * N * d;
@@ -648,8 +679,8 @@ __global__ __launch_bounds__(256) void iso_advance_fp_kernel(IsoView v, TrajCtl*
 #pragma unroll
         for (int i = 0; i < N; ++i) xid[i * d + lane] = xn[i];
       }
-      store_small<N>(v.cG + (size_t(dst) * sB + b) * N * N, G, lane);
-      store_small<N>(v.cLam + (size_t(dst) * sB + b) * N * N, RL, lane);
+      ln::store_rows<N>(v.cG + (size_t(dst) * sB + b) * N * N, G, lane);
+      ln::store_cols<N>(v.cLam + (size_t(dst) * sB + b) * N * N, RL, lane);
       lds_done();
       if (lane == 0) *mergedS = a + 1;
     }
@@ -663,7 +694,7 @@ __global__ __launch_bounds__(256) void iso_advance_fp_kernel(IsoView v, TrajCtl*
 template <int N, bool FP>
 __global__ __launch_bounds__(256) void iso_interp_kernel(IsoView v, const InterpArg* __restrict__ args,
                                                          const IwpConst* __restrict__ Kc) {
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, l = lane & 15;
   const int wv = threadIdx.x >> 6;
   const int b = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv);
   if (b >= v.B) return;
@@ -682,15 +713,17 @@ __global__ __launch_bounds__(256) void iso_interp_kernel(IsoView v, const Interp
     for (int j = lane; j < d; j += kWave)
 #pragma unroll
       for (int i = 0; i < N; ++i) cm[i * d + j] = m1[i * d + j];
-    double R1[N][N];
-    load_small<N>(v.fac + (size_t(arg.s1) * sB + b) * N * N, R1);
-    store_small<N>(v.ck_fac + ck * N * N, R1, lane);
+    const double* f1 = v.fac + (size_t(arg.s1) * sB + b) * N * N;
+    for (int e = lane; e < N * N; e += kWave) v.ck_fac[ck * N * N + e] = f1[e];
     if constexpr (FP) {
-      double G1[N][N], L1[N][N];
-      load_small<N>(v.cG + (size_t(arg.s1) * sB + b) * N * N, G1);
-      load_small<N>(v.cLam + (size_t(arg.s1) * sB + b) * N * N, L1);
-      store_small<N>(v.ck_G + ck * N * N, G1, lane);
-      store_small<N>(v.ck_Lam + ck * N * N, L1, lane);
+      double* g1 = v.cG + (size_t(arg.s1) * sB + b) * N * N;
+      double* l1 = v.cLam + (size_t(arg.s1) * sB + b) * N * N;
+      for (int e = lane; e < N * N; e += kWave) {
+        v.ck_G[ck * N * N + e] = g1[e];
+        v.ck_Lam[ck * N * N + e] = l1[e];
+        g1[e] = (e / N == e % N) ? 1.0 : 0.0;
+        l1[e] = 0.0;
+      }
       double* xi1 = v.cxi + (size_t(arg.s1) * sB + b) * N * d;
       double* cxi = v.ck_xi + ck * N * d;
       for (int j = lane; j < d; j += kWave)
@@ -699,15 +732,6 @@ __global__ __launch_bounds__(256) void iso_interp_kernel(IsoView v, const Interp
           cxi[i * d + j] = xi1[i * d + j];
           xi1[i * d + j] = 0.0;
         }
-#pragma unroll
-      for (int i = 0; i < N; ++i)
-#pragma unroll
-        for (int j = 0; j < N; ++j) {
-          G1[i][j] = (i == j) ? 1.0 : 0.0;
-          L1[i][j] = 0.0;
-        }
-      store_small<N>(v.cG + (size_t(arg.s1) * sB + b) * N * N, G1, lane);
-      store_small<N>(v.cLam + (size_t(arg.s1) * sB + b) * N * N, L1, lane);
     }
     if (lane == 0) {
       v.ck_steps[ck] = arg.steps;
@@ -716,34 +740,40 @@ __global__ __launch_bounds__(256) void iso_interp_kernel(IsoView v, const Interp
     return;
   }
 
+  LanePrior<N> P;
+  load_lane_prior<N>(Kc, P, l);
   const double sigma = v.sigma[size_t(arg.s1) * sB + b];
   const double dt0 = arg.t - arg.t0, dt1 = arg.t1 - arg.t;
-  double p[N], pinv[N], q[N], qinv[N];
-  preconditioner<N>(dt0, K, p, pinv);
-  preconditioner<N>(dt1, K, q, qinv);
+  double p[N], pinv[N], pl, pil;
+  preconditioner_lanes<N>(dt0, P.fact, l, p, pinv, pl, pil);
 
-  double R0[N][N], Rt[N][N], Gt[N][N], RLt[N][N];
-  load_small<N>(v.fac + (size_t(arg.s0) * sB + b) * N * N, R0);
-  iso_time_update<N, FP>(K, R0, p, pinv, sigma, Rt, Gt, RLt);
+  double R0[N], Rt[N], Gt[N], RLt[N];
+  ln::load_cols<N>(v.fac + (size_t(arg.s0) * sB + b) * N * N, R0, l);
+  ln::time_update<N, FP>(P.arow, P.qcol, R0, pinv, pl, pil, sigma, l, Rt, Gt, RLt);
 
   if constexpr (!FP) {
     // filter: the solution at t is the prediction from INTERP_FROM; it becomes the new INTERP_FROM
-    for (int j = lane; j < d; j += kWave) {
+    for (int j0 = 0; j0 < d; j0 += kWave) {
+      const int j = j0 + lane;
+      const bool on = j < d;
+      const int jc = on ? j : d - 1;
       double mp[N];
 #pragma unroll
-      for (int i = 0; i < N; ++i) mp[i] = pinv[i] * m0[i * d + j];
+      for (int i = 0; i < N; ++i) mp[i] = pinv[i] * m0[i * d + jc];
 #pragma unroll
       for (int i = 0; i < N; ++i) {
         double acc = 0.0;
 #pragma unroll
         for (int kk = i; kk < N; ++kk) acc += K.a[i][kk] * mp[kk];
         const double e = p[i] * acc;
-        m0[i * d + j] = e;
-        cm[i * d + j] = e;
+        if (on) {
+          m0[i * d + j] = e;
+          cm[i * d + j] = e;
+        }
       }
     }
-    store_small<N>(v.fac + (size_t(arg.s0) * sB + b) * N * N, Rt, lane);
-    store_small<N>(v.ck_fac + ck * N * N, Rt, lane);
+    ln::store_cols<N>(v.fac + (size_t(arg.s0) * sB + b) * N * N, Rt, lane);
+    ln::store_cols<N>(v.ck_fac + ck * N * N, Rt, lane);
     if (lane == 0) {
       v.sigma[size_t(arg.s0) * sB + b] = sigma;
       v.ck_steps[ck] = arg.steps;
@@ -753,20 +783,25 @@ __global__ __launch_bounds__(256) void iso_interp_kernel(IsoView v, const Interp
   } else {
     // fixedpoint: (i) t0 -> t with merged backward transition, (ii) t -> t1 from an identity
     // transition, (iii) marginalise STEP_FROM through the t1 -> t transition.
-    double Runused[N][N], G1[N][N], RL1[N][N];
-    iso_time_update<N, true>(K, Rt, q, qinv, sigma, Runused, G1, RL1);
+    double q[N], qinv[N], ql, qil;
+    preconditioner_lanes<N>(dt1, P.fact, l, q, qinv, ql, qil);
+    double Runused[N], G1[N], RL1[N];
+    ln::time_update<N, true>(P.arow, P.qcol, Rt, qinv, ql, qil, sigma, l, Runused, G1, RL1);
 
-    double G0[N][N], RL0[N][N];
-    load_small<N>(v.cG + (size_t(arg.s0) * sB + b) * N * N, G0);
-    load_small<N>(v.cLam + (size_t(arg.s0) * sB + b) * N * N, RL0);
+    double G0[N], RL0[N];
+    ln::load_rows<N>(v.cG + (size_t(arg.s0) * sB + b) * N * N, G0, l);
+    ln::load_cols<N>(v.cLam + (size_t(arg.s0) * sB + b) * N * N, RL0, l);
     double* xi0 = v.cxi + (size_t(arg.s0) * sB + b) * N * d;
     double* xi1 = v.cxi + (size_t(arg.s1) * sB + b) * N * d;
     double* cxi = v.ck_xi + ck * N * d;
-    for (int j = lane; j < d; j += kWave) {
+    for (int j0 = 0; j0 < d; j0 += kWave) {
+      const int j = j0 + lane;
+      const bool on = j < d;
+      const int jc = on ? j : d - 1;
       double mo[N], mt[N], mt1[N], tmp[N];
 #pragma unroll
       for (int i = 0; i < N; ++i) {
-        mo[i] = m0[i * d + j];
+        mo[i] = m0[i * d + jc];
         tmp[i] = pinv[i] * mo[i];
       }
 #pragma unroll
@@ -786,76 +821,75 @@ __global__ __launch_bounds__(256) void iso_interp_kernel(IsoView v, const Interp
         mt1[i] = q[i] * acc;  // prediction of t1 from t
       }
       // xi of (t0 -> t), merged with the running transition of INTERP_FROM
-      double xit[N];
+      double xit[N], cx[N];
 #pragma unroll
       for (int i = 0; i < N; ++i) {
-        double acc = mo[i];
-#pragma unroll
-        for (int kk = 0; kk < N; ++kk) acc -= Gt[i][kk] * mt[kk];
-        xit[i] = acc;
+        xit[i] = mo[i];
+        cx[i] = xi0[i * d + jc];
       }
-#pragma unroll
-      for (int i = 0; i < N; ++i) {
-        double acc = xi0[i * d + j];
-#pragma unroll
-        for (int kk = 0; kk < N; ++kk) acc += G0[i][kk] * xit[kk];
-        cxi[i * d + j] = acc;
-      }
+      ln::opaque(Gt);
+      ln::opaque(G0);
+      ln::opaque(G1);
+      ln::matvec_rows<N, -1>(Gt, mt, xit);
+      ln::matvec_rows<N, +1>(G0, xit, cx);
       // xi of (t -> t1); smoothed mean at t
-      double m1v[N];
-#pragma unroll
-      for (int i = 0; i < N; ++i) m1v[i] = m1[i * d + j];
+      double m1v[N], x1[N], ms[N];
 #pragma unroll
       for (int i = 0; i < N; ++i) {
-        double x1 = mt[i], ms = 0.0;
+        m1v[i] = m1[i * d + jc];
+        x1[i] = mt[i];
+        ms[i] = 0.0;
+      }
+      ln::matvec_rows<N, -1>(G1, mt1, x1);
+      ln::matvec_rows<N, +1>(G1, m1v, ms);
+      if (on) {
 #pragma unroll
-        for (int kk = 0; kk < N; ++kk) {
-          x1 -= G1[i][kk] * mt1[kk];
-          ms += G1[i][kk] * m1v[kk];
+        for (int i = 0; i < N; ++i) {
+          cxi[i * d + j] = cx[i];
+          xi1[i * d + j] = x1[i];        // STEP_FROM now remembers how to get back to t
+          cm[i * d + j] = ms[i] + x1[i];  // solution at the checkpoint
+          m0[i * d + j] = mt[i];         // INTERP_FROM <- filtering state at t
+          xi0[i * d + j] = 0.0;          //   ... with an identity backward transition
         }
-        xi1[i * d + j] = x1;         // STEP_FROM now remembers how to get back to t
-        cm[i * d + j] = ms + x1;     // solution at the checkpoint
-        m0[i * d + j] = mt[i];       // INTERP_FROM <- filtering state at t
-        xi0[i * d + j] = 0.0;        //   ... with an identity backward transition
       }
     }
     // checkpoint factor: qr_r([R1 G1^T ; RL1])
-    double R1[N][N], Rs[N][N];
-    load_small<N>(v.fac + (size_t(arg.s1) * sB + b) * N * N, R1);
+    {
+      double R1[N], X[N], Ts[N], PT[N], PB[N];
+      ln::load_cols<N>(v.fac + (size_t(arg.s1) * sB + b) * N * N, R1, l);
 #pragma unroll
-    for (int c = 0; c < N; ++c)
-#pragma unroll
-      for (int i = 0; i < N; ++i) Rs[c][i] = (i >= c) ? RL1[c][i] : 0.0;
-#pragma unroll
-    for (int c = 0; c < N; ++c) {
-      double x[N];
-#pragma unroll
-      for (int i = 0; i < N; ++i) {
+      for (int c = 0; c < N; ++c) {  // row c of R1 G1^T, col-lane
         double acc = 0.0;
-#pragma unroll
-        for (int kk = 0; kk < N; ++kk) acc += R1[c][kk] * G1[i][kk];
-        x[i] = acc;
+        ln::sfor<0, N>([&](auto kc) PNODE_LAMBDA_INLINE {
+          constexpr int kk = decltype(kc)::value;
+          acc += ln::bcast<kk>(R1[c]) * G1[kk];
+        });
+        X[c] = acc;
       }
-      givens_rotate_in<N>(Rs, x);
+#pragma unroll
+      for (int r = 0; r < N; ++r) Ts[r] = (l >= r) ? RL1[r] : 0.0;
+      ln::qr_stack<N, false>(Ts, X, PT, PB, l);
+      ln::store_cols<N>(v.ck_fac + ck * N * N, Ts, lane);
     }
-    store_small<N>(v.ck_fac + ck * N * N, Rs, lane);
     // checkpoint backward transition = merged (t0 -> t) transition
-    iso_merge_small<N>(G0, RL0, Gt, RLt);
-    store_small<N>(v.ck_G + ck * N * N, Gt, lane);
-    store_small<N>(v.ck_Lam + ck * N * N, RLt, lane);
+    ln::merge<N>(G0, RL0, Gt, RLt, l);
+    ln::store_rows<N>(v.ck_G + ck * N * N, Gt, lane);
+    ln::store_cols<N>(v.ck_Lam + ck * N * N, RLt, lane);
     // STEP_FROM transition <- (t1 -> t); INTERP_FROM <- (filter state at t, identity)
-    store_small<N>(v.cG + (size_t(arg.s1) * sB + b) * N * N, G1, lane);
-    store_small<N>(v.cLam + (size_t(arg.s1) * sB + b) * N * N, RL1, lane);
-    store_small<N>(v.fac + (size_t(arg.s0) * sB + b) * N * N, Rt, lane);
+    ln::store_rows<N>(v.cG + (size_t(arg.s1) * sB + b) * N * N, G1, lane);
+    ln::store_cols<N>(v.cLam + (size_t(arg.s1) * sB + b) * N * N, RL1, lane);
+    ln::store_cols<N>(v.fac + (size_t(arg.s0) * sB + b) * N * N, Rt, lane);
+    {
+      double* g0 = v.cG + (size_t(arg.s0) * sB + b) * N * N;
+      double* l0 = v.cLam + (size_t(arg.s0) * sB + b) * N * N;
+      if (lane < N) {
 #pragma unroll
-    for (int i = 0; i < N; ++i)
-#pragma unroll
-      for (int j = 0; j < N; ++j) {
-        G0[i][j] = (i == j) ? 1.0 : 0.0;
-        RL0[i][j] = 0.0;
+        for (int c = 0; c < N; ++c) {
+          g0[lane * N + c] = (lane == c) ? 1.0 : 0.0;
+          l0[lane * N + c] = 0.0;
+        }
       }
-    store_small<N>(v.cG + (size_t(arg.s0) * sB + b) * N * N, G0, lane);
-    store_small<N>(v.cLam + (size_t(arg.s0) * sB + b) * N * N, RL0, lane);
+    }
     if (lane == 0) {
       v.sigma[size_t(arg.s0) * sB + b] = sigma;
       v.ck_steps[ck] = arg.steps;
@@ -916,7 +950,7 @@ template <int N>
 __global__ __launch_bounds__(256) void iso_offgrid_kernel(IsoView v, const OffgridArg* __restrict__ qs, int Q,
                                                           const double* __restrict__ init, const double* __restrict__ smoothed,
                                                           const IwpConst* __restrict__ Kc, double* __restrict__ out) {
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, l = lane & 15;
   const int wv = threadIdx.x >> 6;
   const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv);
   if (item >= v.B * Q) return;
@@ -935,24 +969,26 @@ __global__ __launch_bounds__(256) void iso_offgrid_kernel(IsoView v, const Offgr
   }
   const double* m0 = (c == 0) ? init + size_t(b) * N * d : v.ck_mean + (size_t(b) * v.K + c - 1) * N * d;
   const double sigma = v.ck_sigma[size_t(b) * v.K + c];
-  double p[N], pinv[N], q[N], qinv[N];
-  preconditioner<N>(a.t - a.t_lo, K, p, pinv);
-  preconditioner<N>(a.t_hi - a.t, K, q, qinv);
-  double R0[N][N], Rt[N][N], Gt[N][N], RLt[N][N], Ru[N][N], G1[N][N], RL1[N][N];
+  LanePrior<N> P;
+  load_lane_prior<N>(Kc, P, l);
+  double p[N], pinv[N], pl, pil, q[N], qinv[N], ql, qil;
+  preconditioner_lanes<N>(a.t - a.t_lo, P.fact, l, p, pinv, pl, pil);
+  preconditioner_lanes<N>(a.t_hi - a.t, P.fact, l, q, qinv, ql, qil);
+  double R0[N], Rt[N], Gt[N], RLt[N], Ru[N], G1[N], RL1[N];
+  ln::load_cols<N>(v.ck_fac + (size_t(b) * v.K + (c > 0 ? c - 1 : 0)) * N * N, R0, l);
   if (c == 0) {
 #pragma unroll
-    for (int i = 0; i < N; ++i)
-#pragma unroll
-      for (int j = 0; j < N; ++j) R0[i][j] = 0.0;
-  } else {
-    load_small<N>(v.ck_fac + (size_t(b) * v.K + c - 1) * N * N, R0);
+    for (int i = 0; i < N; ++i) R0[i] = 0.0;
   }
-  iso_time_update<N, false>(K, R0, p, pinv, sigma, Rt, Gt, RLt);
-  iso_time_update<N, true>(K, Rt, q, qinv, sigma, Ru, G1, RL1);
-  for (int j = lane; j < d; j += kWave) {
+  ln::time_update<N, false>(P.arow, P.qcol, R0, pinv, pl, pil, sigma, l, Rt, Gt, RLt);
+  ln::time_update<N, true>(P.arow, P.qcol, Rt, qinv, ql, qil, sigma, l, Ru, G1, RL1);
+  for (int j0 = 0; j0 < d; j0 += kWave) {
+    const int j = j0 + lane;
+    const bool on = j < d;
+    const int jc = on ? j : d - 1;
     double mt[N], mt1[N], tmp[N];
 #pragma unroll
-    for (int i = 0; i < N; ++i) tmp[i] = pinv[i] * m0[i * d + j];
+    for (int i = 0; i < N; ++i) tmp[i] = pinv[i] * m0[i * d + jc];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       double acc = 0.0;
@@ -969,12 +1005,17 @@ __global__ __launch_bounds__(256) void iso_offgrid_kernel(IsoView v, const Offgr
       for (int kk = i; kk < N; ++kk) acc += K.a[i][kk] * tmp[kk];
       mt1[i] = q[i] * acc;  // prediction of t_hi from t
     }
+    double diff[N], acc[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-      double acc = mt[i];
+      diff[i] = ms[i * d + jc] - mt1[i];
+      acc[i] = mt[i];
+    }
+    ln::opaque(G1);
+    ln::matvec_rows<N, +1>(G1, diff, acc);
+    if (on) {
 #pragma unroll
-      for (int kk = 0; kk < N; ++kk) acc += G1[i][kk] * (ms[kk * d + j] - mt1[kk]);
-      o[i * d + j] = acc;
+      for (int i = 0; i < N; ++i) o[i * d + j] = acc[i];
     }
   }
 }
@@ -996,8 +1037,7 @@ __global__ __launch_bounds__(256) void iso_sample_kernel(IsoView v, const int32_
   const int d = v.d;
   const double* e = eps + size_t(item) * P * N * d;  // P points per sample (>= num_filled + 1): the caller's stride, not the store's capacity
   double* o = out + size_t(item) * P * N * d;
-  double RT[N][N];
-  load_small<N>(v.ck_fac + (size_t(b) * v.K + nf - 1) * N * N, RT);
+  const double* RT = v.ck_fac + (size_t(b) * v.K + nf - 1) * N * N;  // (wave-uniform address: scalar loads)
   for (int j = lane; j < d; j += kWave) {
     double x[N];
     const double* mT = v.ck_mean + (size_t(b) * v.K + nf - 1) * N * d;
@@ -1005,7 +1045,7 @@ __global__ __launch_bounds__(256) void iso_sample_kernel(IsoView v, const int32_
     for (int i = 0; i < N; ++i) {
       double acc = mT[i * d + j];
 #pragma unroll
-      for (int kk = 0; kk <= i; ++kk) acc += RT[kk][i] * e[(size_t(nf) * N + kk) * d + j];  // R upper: (R^T e)_i = sum_{k <= i} R[k][i] e_k
+      for (int kk = 0; kk <= i; ++kk) acc += RT[kk * N + i] * e[(size_t(nf) * N + kk) * d + j];  // R upper: (R^T e)_i = sum_{k <= i} R[k][i] e_k
       x[i] = acc;
       o[(size_t(nf) * N + i) * d + j] = acc;
     }
@@ -1099,29 +1139,23 @@ static void launch_advance_n(const IsoView& v, TrajCtl* ctl, const IwpConst* K, 
   }
   const int blocks = (v.B + 3) / 4;
   // Fixed-point smoother, d <= 64, on request (pnode_set_smoother_pipeline): a workgroup per trajectory (filter wavefront + three
-  // smoother wavefronts) shortens the chain of a trajectory 1.6x but holds a CU (two fit up to nu = 3); with more trajectories than fit
+  // smoother wavefronts) shortens the chain of a trajectory but holds more of a CU; with more trajectories than fit
   // at once and equal work per trajectory the one-wavefront kernel (four trajectories per workgroup, every SIMD busy) has the
   // higher throughput. Both take the same decisions bit for bit (the filter arithmetic is the same code); the smoothed means agree
   // to rounding (the compiler contracts the multiply-adds of the transitions differently in the two kernels) -- which is why the
   // choice is the caller's and never made from the batch size: a shard of a batch gives the bits of the unsharded solve.
-  // From nu = 5 on the one-wavefront kernel of the smoother (256 VGPRs + more than 100 spilled to AGPRs) ended in a memory
-  // access fault on the MI355X (iso_advance_kernel<6, true, 1>; a branch-free form of the Givens rotations moved the fault to
-  // nu = 4 instead of removing it: not understood, no such kernel is launched): the pipelined kernel serves those shapes.
-  const bool pipelined = v.fp_pipeline == 1 || N >= 6;
-  if (v.fixedpoint && v.d <= kWave && pipelined) {
+  if (v.fixedpoint && v.d <= kWave && v.fp_pipeline == 1) {
     hipLaunchKernelGGL((iso_advance_fp_kernel<N>), dim3(v.B), dim3(256), iso_fp_shm_doubles(N, v.k, v.d) * sizeof(double), s, v, ctl, K, cp);
     return;
   }
-  if (v.fixedpoint) {
-    if constexpr (N <= 5)  // (N >= 6, d > 64 is refused by iso_advance_supported: see above)
-      hipLaunchKernelGGL((iso_advance_kernel<N, true, 1>), dim3(blocks), dim3(256), iso_shm(v, 4), s, v, ctl, K, cp);
-  } else {
+  if (v.fixedpoint)
+    hipLaunchKernelGGL((iso_advance_kernel<N, true, 1>), dim3(blocks), dim3(256), iso_shm(v, 4), s, v, ctl, K, cp);
+  else
     hipLaunchKernelGGL((iso_advance_kernel<N, false, 1>), dim3(blocks), dim3(256), iso_shm(v, 4), s, v, ctl, K, cp);
-  }
 }
-// The device-resident controller exists for every shape except the fixed-point smoother with nu >= 5 beyond d = 64 (see
-// launch_advance_n): the caller falls back to the host controller there.
-bool iso_advance_supported(const IsoView& v) { return !(v.fixedpoint && v.n >= 6 && v.d > kWave); }
+// The device-resident controller serves every shape of the isotropic model (r03 refused the fixed-point smoother with nu >= 5
+// beyond d = 64: a work-around for the fault explained in DESIGN.md section 6b, gone with its cause).
+bool iso_advance_supported(const IsoView&) { return true; }
 
 void iso_launch_advance(const IsoView& v, TrajCtl* ctl, const IwpConst* K, const ControlParams& cp, hipStream_t s) {
 #define CALL(NN) launch_advance_n<NN>(v, ctl, K, cp, s)

@@ -1,13 +1,21 @@
-#!/usr/bin/env python3
-"""Summarise hipcc's -Rpass-analysis=kernel-resource-usage remarks: registers, scratch, occupancy and LDS per kernel.
-  python scripts/kernel_resources.py file.res [...]   (file.res = stderr of hipcc ... -Rpass-analysis=kernel-resource-usage)"""
+"""Tabulate the compiler's resource report of a HIP translation unit (hipcc -Rpass-analysis=kernel-resource-usage ... 2> file):
+registers, AGPRs (spills of non-MFMA kernels), scratch bytes per lane, occupancy.  usage: python scripts/kernel_resources.py report.txt"""
 import re
+import subprocess
 import sys
 
-for f in sys.argv[1:]:
-    txt = open(f).read()
+
+def rows(path):
+    txt = open(path).read()
+    out = []
     for blk in txt.split("Function Name: ")[1:]:
-        name = re.sub(r"_ZN5pnode\d+", "", blk.split()[0])[:44]
-        get = lambda k: re.search(k + r": (\d+)", blk).group(1)
-        print("%-46s VGPR %s AGPR %s scratch %s occ %s LDS %s" % (name, get("VGPRs"), get("AGPRs"), get(r"ScratchSize \[bytes/lane\]"),
-                                                               get(r"Occupancy \[waves/SIMD\]"), get(r"LDS Size \[bytes/block\]")))
+        name = blk.split()[0]
+        dem = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip().split("(")[0].replace("void pnode::", "")
+        g = lambda k: int(re.search(k + r": (\S+)", blk).group(1))
+        out.append((dem, g("TotalSGPRs"), g("VGPRs"), g("AGPRs"), g(r"ScratchSize \[bytes/lane\]"), g(r"Occupancy \[waves/SIMD\]")))
+    return out
+
+
+if __name__ == "__main__":
+    for r in rows(sys.argv[1]):
+        print("%-46s sgpr %3d vgpr %3d agpr %3d scratch %4d occupancy %d" % r)
