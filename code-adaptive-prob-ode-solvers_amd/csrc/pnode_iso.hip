@@ -38,7 +38,7 @@ __device__ __forceinline__ double team_sum(double v, double* red, int wteam) {
   return t;
 }
 
-// Per-lane constants of a kernel: row l of Abar, column l of chol(Qbar)^T, (nu - l)!  (l = lane & 15)
+// Per-lane constants of a kernel: row l of Abar, column l of chol(Qbar)^T, (nu - l)!  (l = ln::col_index<N>(lane))
 template <int N>
 struct LanePrior {
   double arow[N], qcol[N], fact;
@@ -46,13 +46,12 @@ struct LanePrior {
 template <int N>
 __device__ __forceinline__ void load_lane_prior(const IwpConst* __restrict__ Kc, LanePrior<N>& P, int l) {
   ln::load_prior<N>(Kc, P.arow, P.qcol, l);
-  const double f = Kc->fact[l < N ? l : N - 1];
-  P.fact = l < N ? f : 1.0;
+  P.fact = Kc->fact[l];
 }
 
 // p_i = dt^(nu-i+1/2) / (nu-i)!,  pinv_i = 1/p_i   (probdiffeq preconditioner_diagonal): lane i forms its own pair (one
 // division each, all lanes side by side; the same sequence of multiplications as preconditioner() of pnode_common.hpp), the
-// uniform arrays come from row broadcasts. pl / pil: my lane's entries (0 beyond n).
+// uniform arrays come from row broadcasts. pl / pil: my lane's entries.
 template <int N>
 __device__ __forceinline__ void preconditioner_lanes(double dt, double fact, int l, double (&p)[N], double (&pinv)[N], double& pl,
                                                      double& pil) {
@@ -66,8 +65,8 @@ __device__ __forceinline__ void preconditioner_lanes(double dt, double fact, int
     p[i] = ln::bcast<i>(mine);
     pinv[i] = ln::bcast<i>(mine_inv);
   });
-  pl = l < N ? mine : 0.0;
-  pil = l < N ? mine_inv : 0.0;
+  pl = mine;
+  pil = mine_inv;
 }
 
 // Correction on z = 0 (isotropic EKF0): F = column k of Rm (row k of L^-), gain, projector-form update of the factor in place.
@@ -96,7 +95,7 @@ __device__ __forceinline__ double correct_factor(double (&Rm)[N], int k) {
 // controller) wraps it in a load and a store; the device-resident controller (iso_advance_kernel) keeps the last accepted
 // state in registers over all the attempts of a launch and writes a state to its slot only when it is accepted: an attempt
 // then waits for no global memory at all.
-// State: m[N]: my ODE dimension of the mean (lanes < d, 0 beyond), R[N]: the factor, col-lane, sigma.
+// State: m[N]: my ODE dimension of the mean (lanes beyond d repeat dimension d - 1), R[N]: the factor, col-lane, sigma.
 // ---------------------------------------------------------------------------------------------
 template <int N>
 __device__ __forceinline__ void iso_copy_regs(double (&dm)[N], double (&dR)[N], double& dsig, const double (&sm)[N],
@@ -116,11 +115,8 @@ __device__ __forceinline__ void iso_load_regs(const IsoView& v, int b, int lane,
   const double* msrc = v.mean + (size_t(slot) * sB + b) * N * d;
   const int jc = lane < d ? lane : d - 1;
 #pragma unroll
-  for (int i = 0; i < N; ++i) {
-    const double x = msrc[i * d + jc];
-    m[i] = lane < d ? x : 0.0;
-  }
-  ln::load_cols<N>(v.fac + (size_t(slot) * sB + b) * N * N, R, lane & 15);
+  for (int i = 0; i < N; ++i) m[i] = msrc[i * d + jc];
+  ln::load_cols<N>(v.fac + (size_t(slot) * sB + b) * N * N, R, ln::col_index<N>(lane));
   sigma = v.sigma[size_t(slot) * sB + b];
 }
 
@@ -130,12 +126,11 @@ __device__ __forceinline__ void iso_store_regs(const IsoView& v, int b, int lane
   const int d = v.d;
   const size_t sB = size_t(v.B);
   double* mdst = v.mean + (size_t(slot) * sB + b) * N * d;
-  if (lane < d) {
+  const int jc = lane < d ? lane : d - 1;
 #pragma unroll
-    for (int i = 0; i < N; ++i) mdst[i * d + lane] = m[i];
-  }
-  ln::store_cols<N>(v.fac + (size_t(slot) * sB + b) * N * N, R, lane);
-  if (lane == 0) v.sigma[size_t(slot) * sB + b] = sigma;
+  for (int i = 0; i < N; ++i) mdst[i * d + jc] = m[i];
+  ln::store_cols<N>(v.fac + (size_t(slot) * sB + b) * N * N, R, ln::col_index<N>(lane));
+  v.sigma[size_t(slot) * sB + b] = sigma;
 }
 
 // One attempted step from the state `s`. Returns the normalised error norm (a scalar the compiler knows to be uniform).
@@ -143,7 +138,7 @@ template <int N>
 __device__ __forceinline__ double iso_attempt_regs(const IsoView& v, const IwpConst& K, const LanePrior<N>& P, int b, int lane, double dt,
                                                    double t, const double (&sm)[N], const double (&sR)[N], double ssigma, double (&om)[N],
                                                    double (&oR)[N], double& osigma, double atol, double rtol, double* ybuf, double (&me)[N]) {
-  const int d = v.d, k = v.k, l = lane & 15;
+  const int d = v.d, k = v.k, l = ln::col_index<N>(lane);
   const bool on = lane < d;
   const int jc = on ? lane : d - 1;
   double p[N], pinv[N], pl, pil;
@@ -161,7 +156,7 @@ __device__ __forceinline__ double iso_attempt_regs(const IsoView& v, const IwpCo
       for (int kk = i; kk < N; ++kk) acc += K.a[i][kk] * mp[kk];
       const double e = p[i] * acc;
       me[i] = e;
-      if (on && i < k) ybuf[i * d + lane] = e;
+      if (i < k) ybuf[i * d + jc] = e;
     }
   }
   __builtin_amdgcn_wave_barrier();
@@ -179,9 +174,8 @@ __device__ __forceinline__ double iso_attempt_regs(const IsoView& v, const IwpCo
     mek = (i == k) ? me[i] : mek;
     pk = (i == k) ? p[i] : pk;
   }
-  const double zall = mek - vf_f(ctx, ybuf, jc, tnew);
-  const double z = on ? zall : 0.0;  // (lanes beyond d keep a zero column)
-  const double zz = ln::uniform(wave_sum(z * z));  // (uniform by construction; said to the compiler as well)
+  const double z = mek - vf_f(ctx, ybuf, jc, tnew);
+  const double zz = ln::uniform(wave_sum(on ? z * z : 0.0));  // (uniform by construction; said to the compiler as well)
   __builtin_amdgcn_wave_barrier();  // (ybuf is rewritten by the next attempt)
 
   // --- calibration + error estimate
@@ -215,7 +209,7 @@ template <int N, bool FP, int W>
 __device__ __forceinline__ double iso_attempt(const IsoView& v, const IwpConst& K, const LanePrior<N>& P, int b, int lane,
                                               const StepArg& arg, double* ybuf, double* zbuf, double* red) {
   constexpr int kTeam = kWave * W;
-  const int wteam = lane >> 6, l = lane & 15;
+  const int wteam = lane >> 6, l = ln::col_index<N>(lane);
   const int d = v.d, k = v.k;
   if constexpr (W == 1 && !FP) {
     if (d <= kWave) {  // one ODE dimension per lane: the register form above
@@ -250,10 +244,8 @@ __device__ __forceinline__ double iso_attempt(const IsoView& v, const IwpConst& 
 #pragma unroll
       for (int kk = i; kk < N; ++kk) acc += K.a[i][kk] * mp[kk];
       const double e = p[i] * acc;
-      if (on) {
-        mdst[i * d + j] = e;
-        if (i < k) ybuf[i * d + j] = e;
-      }
+      mdst[i * d + jc] = e;
+      if (i < k) ybuf[i * d + jc] = e;
     }
   }
   if constexpr (W == 1) {
@@ -274,10 +266,8 @@ __device__ __forceinline__ double iso_attempt(const IsoView& v, const IwpConst& 
     const bool on = j < d;
     const int jc = on ? j : d - 1;
     const double z = mdst[k * d + jc] - vf_f(ctx, ybuf, jc, tnew);
-    if (on) {
-      zbuf[j] = z;
-      zz += z * z;
-    }
+    zbuf[jc] = z;
+    zz += on ? z * z : 0.0;
   }
   zz = ln::uniform(team_sum<W>(zz, red, wteam));
 
@@ -318,19 +308,17 @@ __device__ __forceinline__ double iso_attempt(const IsoView& v, const IwpConst& 
       ln::opaque(G0);
       ln::matvec_rows<N, -1>(G, me, xi);
       ln::matvec_rows<N, +1>(G0, xi, acc);
-      if (on) {
 #pragma unroll
-        for (int i = 0; i < N; ++i) xid[i * d + j] = acc[i];
-      }
+      for (int i = 0; i < N; ++i) xid[i * d + jc] = acc[i];
     }
     ln::merge<N>(G0, RL0, G, RL, l);
-    ln::store_rows<N>(v.cG + (size_t(arg.dst) * sB + b) * N * N, G, lane);
-    ln::store_cols<N>(v.cLam + (size_t(arg.dst) * sB + b) * N * N, RL, lane);
+    ln::store_rows<N>(v.cG + (size_t(arg.dst) * sB + b) * N * N, G, l);
+    ln::store_cols<N>(v.cLam + (size_t(arg.dst) * sB + b) * N * N, RL, l);
   }
 
   // --- correction on z = 0: F = row k of L^- = column k of Rm; gain; projector-form update
   const double gain = correct_factor<N>(Rm, k);
-  ln::store_cols<N>(v.fac + (size_t(arg.dst) * sB + b) * N * N, Rm, lane);
+  ln::store_cols<N>(v.fac + (size_t(arg.dst) * sB + b) * N * N, Rm, l);
   double gu[N];
   ln::sfor<0, N>([&](auto ic) PNODE_LAMBDA_INLINE {
     constexpr int i = decltype(ic)::value;
@@ -349,14 +337,14 @@ __device__ __forceinline__ double iso_attempt(const IsoView& v, const IwpConst& 
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       const double mnew = mdst[i * d + jc] - gu[i] * z;
-      if (on) mdst[i * d + j] = mnew;
+      mdst[i * d + jc] = mnew;
       if (i == 0) u0 = mnew;
     }
     const double rel = err / (atol + rtol * fabs(u0));
     acc2 += on ? rel * rel : 0.0;
   }
   acc2 = team_sum<W>(acc2, red, wteam);
-  if (lane == 0) v.sigma[size_t(arg.dst) * sB + b] = sigma;
+  v.sigma[size_t(arg.dst) * sB + b] = sigma;
   return ln::uniform(sqrt(acc2 / double(d)));
 }
 
@@ -375,9 +363,9 @@ __global__ __launch_bounds__(256) void iso_step_kernel(IsoView v, const StepArg*
   double* zbuf = ybuf + size_t(v.k) * v.d;                            // [d] residual
   double* red = zbuf + v.d;                                           // [W]
   LanePrior<N> P;
-  load_lane_prior<N>(Kc, P, lane & 15);
+  load_lane_prior<N>(Kc, P, ln::col_index<N>(lane));
   const double e = iso_attempt<N, FP, W>(v, *Kc, P, b, lane, arg, ybuf, zbuf, red);
-  if (lane == 0) v.errnorm[b] = e;
+  v.errnorm[b] = e;
 }
 
 // Device-resident controller (opt-in): every wavefront runs the accept/reject loop and the PI
@@ -430,7 +418,7 @@ __global__ __launch_bounds__(256) void iso_advance_kernel(IsoView v, TrajCtl* __
   double* zbuf = ybuf + size_t(v.k) * v.d;
   double* red = zbuf + v.d;
   LanePrior<N> P;
-  load_lane_prior<N>(Kc, P, lane & 15);
+  load_lane_prior<N>(Kc, P, ln::col_index<N>(lane));
   int iters = 0;
   c.status = 0;
   bool in_registers = false;
@@ -473,7 +461,7 @@ __global__ __launch_bounds__(256) void iso_advance_kernel(IsoView v, TrajCtl* __
     }
   }
   if (c.status == 0) c.status = (c.t_sf + cp.numerical_zero >= c.t_stop) ? 1 : 3;
-  if (lane == 0) ctl[b] = c;
+  ctl[b] = c;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -502,7 +490,7 @@ __global__ __launch_bounds__(256) void iso_advance_fp_kernel(IsoView v, TrajCtl*
                                                              ControlParams cp) {
   extern __shared__ double smem[];
   constexpr int EN = iso_fp_entry_doubles<N>();
-  const int tid = threadIdx.x, lane = tid & 63, l = lane & 15;
+  const int tid = threadIdx.x, lane = tid & 63, l = ln::col_index<N>(lane);
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x;
   if (b >= v.B) return;
@@ -535,10 +523,7 @@ __global__ __launch_bounds__(256) void iso_advance_fp_kernel(IsoView v, TrajCtl*
     const double* xi0 = v.cxi + (size_t(c.s_sf) * sB + b) * N * d;
     const int jc = lane < d ? lane : d - 1;
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-      const double x = xi0[i * d + jc];
-      runX[i * kWave + lane] = lane < d ? x : 0.0;
-    }
+    for (int i = 0; i < N; ++i) runX[i * kWave + lane] = xi0[i * d + jc];
   }
   __syncthreads();  // the only workgroup barrier
   LanePrior<N> P;
@@ -581,20 +566,18 @@ __global__ __launch_bounds__(256) void iso_advance_fp_kernel(IsoView v, TrajCtl*
           }
         }
         double* ent = ring + (acc % kFpRing) * EN;
-        ln::store_cols<N>(ent, cR, lane);
+        ln::store_cols<N>(ent, cR, l);
 #pragma unroll
         for (int i = 0; i < N; ++i) {
           ent[N * N + i * kWave + lane] = cm[i];
           ent[N * N + N * kWave + i * kWave + lane] = me[i];
         }
-        if (lane == 0) {
-          ent[EN - 4] = dt;
-          ent[EN - 3] = nsig;
-          ent[EN - 2] = double(dst);
-        }
+        ent[EN - 4] = dt;  // (uniform values: every lane writes them)
+        ent[EN - 3] = nsig;
+        ent[EN - 2] = double(dst);
         lds_done();
         ++acc;
-        if (lane == 0) *pushedS = acc;
+        *pushedS = acc;
         iso_store_regs<N>(v, b, lane, dst, nm, nR, nsig);
         iso_copy_regs<N>(cm, cR, csig, nm, nR, nsig);
       }
@@ -605,10 +588,8 @@ __global__ __launch_bounds__(256) void iso_advance_fp_kernel(IsoView v, TrajCtl*
       }
     }
     if (c.status == 0) c.status = (c.t_sf + cp.numerical_zero >= c.t_stop) ? 1 : 3;
-    if (lane == 0) {
-      *totalS = acc;
-      ctl[b] = c;
-    }
+    *totalS = acc;
+    ctl[b] = c;
   } else {
     // ---------------- backward transitions of the accepted steps a = wv - 1, wv + 2, .. and their composition in order
 #pragma unroll 1
@@ -670,19 +651,18 @@ __global__ __launch_bounds__(256) void iso_advance_fp_kernel(IsoView v, TrajCtl*
       ln::matvec_rows<N, +1>(G0, xi, xn);
       ln::merge<N>(G0, RL0, G, RL, l);
       lds_done();  // (my reads of the running transition are complete before it is overwritten)
-      ln::store_rows<N>(runG, G, lane);
-      ln::store_cols<N>(runL, RL, lane);
+      ln::store_rows<N>(runG, G, l);
+      ln::store_cols<N>(runL, RL, l);
 #pragma unroll
       for (int i = 0; i < N; ++i) runX[i * kWave + lane] = xn[i];
       double* xid = v.cxi + (size_t(dst) * sB + b) * N * d;
-      if (lane < d) {
+      const int jc = lane < d ? lane : d - 1;
 #pragma unroll
-        for (int i = 0; i < N; ++i) xid[i * d + lane] = xn[i];
-      }
-      ln::store_rows<N>(v.cG + (size_t(dst) * sB + b) * N * N, G, lane);
-      ln::store_cols<N>(v.cLam + (size_t(dst) * sB + b) * N * N, RL, lane);
+      for (int i = 0; i < N; ++i) xid[i * d + jc] = xn[i];
+      ln::store_rows<N>(v.cG + (size_t(dst) * sB + b) * N * N, G, l);
+      ln::store_cols<N>(v.cLam + (size_t(dst) * sB + b) * N * N, RL, l);
       lds_done();
-      if (lane == 0) *mergedS = a + 1;
+      *mergedS = a + 1;
     }
   }
 }
@@ -694,7 +674,7 @@ __global__ __launch_bounds__(256) void iso_advance_fp_kernel(IsoView v, TrajCtl*
 template <int N, bool FP>
 __global__ __launch_bounds__(256) void iso_interp_kernel(IsoView v, const InterpArg* __restrict__ args,
                                                          const IwpConst* __restrict__ Kc) {
-  const int lane = threadIdx.x & 63, l = lane & 15;
+  const int lane = threadIdx.x & 63, l = ln::col_index<N>(lane);
   const int wv = threadIdx.x >> 6;
   const int b = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv);
   if (b >= v.B) return;
@@ -710,33 +690,41 @@ __global__ __launch_bounds__(256) void iso_interp_kernel(IsoView v, const Interp
 
   if (arg.at_step) {
     // checkpoint coincides with STEP_FROM: store it; fixedpoint resets the backward transition
-    for (int j = lane; j < d; j += kWave)
-#pragma unroll
-      for (int i = 0; i < N; ++i) cm[i * d + j] = m1[i * d + j];
+    // (wave-uniform trip counts, clamped indices, unpredicated stores: the duplicate lanes repeat their neighbour's copy)
+    const int nd = N * d;
+    for (int e0 = 0; e0 < nd; e0 += kWave) {
+      const int e = e0 + lane < nd ? e0 + lane : nd - 1;
+      cm[e] = m1[e];
+    }
     const double* f1 = v.fac + (size_t(arg.s1) * sB + b) * N * N;
-    for (int e = lane; e < N * N; e += kWave) v.ck_fac[ck * N * N + e] = f1[e];
+    for (int e0 = 0; e0 < N * N; e0 += kWave) {
+      const int e = e0 + lane < N * N ? e0 + lane : N * N - 1;
+      v.ck_fac[ck * N * N + e] = f1[e];
+    }
     if constexpr (FP) {
       double* g1 = v.cG + (size_t(arg.s1) * sB + b) * N * N;
       double* l1 = v.cLam + (size_t(arg.s1) * sB + b) * N * N;
-      for (int e = lane; e < N * N; e += kWave) {
-        v.ck_G[ck * N * N + e] = g1[e];
-        v.ck_Lam[ck * N * N + e] = l1[e];
+      for (int e0 = 0; e0 < N * N; e0 += kWave) {
+        const int e = e0 + lane < N * N ? e0 + lane : N * N - 1;
+        const double gv = g1[e], lv = l1[e];
+        v.ck_G[ck * N * N + e] = gv;
+        v.ck_Lam[ck * N * N + e] = lv;
+        __builtin_amdgcn_wave_barrier();  // (the duplicate lanes have read the entry before anyone resets it)
         g1[e] = (e / N == e % N) ? 1.0 : 0.0;
         l1[e] = 0.0;
       }
       double* xi1 = v.cxi + (size_t(arg.s1) * sB + b) * N * d;
       double* cxi = v.ck_xi + ck * N * d;
-      for (int j = lane; j < d; j += kWave)
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-          cxi[i * d + j] = xi1[i * d + j];
-          xi1[i * d + j] = 0.0;
-        }
+      for (int e0 = 0; e0 < nd; e0 += kWave) {
+        const int e = e0 + lane < nd ? e0 + lane : nd - 1;
+        const double x = xi1[e];
+        cxi[e] = x;
+        __builtin_amdgcn_wave_barrier();
+        xi1[e] = 0.0;
+      }
     }
-    if (lane == 0) {
-      v.ck_steps[ck] = arg.steps;
-      v.ck_sigma[ck] = v.sigma[size_t(arg.s1) * sB + b];
-    }
+    v.ck_steps[ck] = arg.steps;
+    v.ck_sigma[ck] = v.sigma[size_t(arg.s1) * sB + b];
     return;
   }
 
@@ -766,19 +754,15 @@ __global__ __launch_bounds__(256) void iso_interp_kernel(IsoView v, const Interp
 #pragma unroll
         for (int kk = i; kk < N; ++kk) acc += K.a[i][kk] * mp[kk];
         const double e = p[i] * acc;
-        if (on) {
-          m0[i * d + j] = e;
-          cm[i * d + j] = e;
-        }
+        m0[i * d + jc] = e;
+        cm[i * d + jc] = e;
       }
     }
-    ln::store_cols<N>(v.fac + (size_t(arg.s0) * sB + b) * N * N, Rt, lane);
-    ln::store_cols<N>(v.ck_fac + ck * N * N, Rt, lane);
-    if (lane == 0) {
-      v.sigma[size_t(arg.s0) * sB + b] = sigma;
-      v.ck_steps[ck] = arg.steps;
-      v.ck_sigma[ck] = sigma;
-    }
+    ln::store_cols<N>(v.fac + (size_t(arg.s0) * sB + b) * N * N, Rt, l);
+    ln::store_cols<N>(v.ck_fac + ck * N * N, Rt, l);
+    v.sigma[size_t(arg.s0) * sB + b] = sigma;
+    v.ck_steps[ck] = arg.steps;
+    v.ck_sigma[ck] = sigma;
     return;
   } else {
     // fixedpoint: (i) t0 -> t with merged backward transition, (ii) t -> t1 from an identity
@@ -842,15 +826,13 @@ __global__ __launch_bounds__(256) void iso_interp_kernel(IsoView v, const Interp
       }
       ln::matvec_rows<N, -1>(G1, mt1, x1);
       ln::matvec_rows<N, +1>(G1, m1v, ms);
-      if (on) {
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
-          cxi[i * d + j] = cx[i];
-          xi1[i * d + j] = x1[i];        // STEP_FROM now remembers how to get back to t
-          cm[i * d + j] = ms[i] + x1[i];  // solution at the checkpoint
-          m0[i * d + j] = mt[i];         // INTERP_FROM <- filtering state at t
-          xi0[i * d + j] = 0.0;          //   ... with an identity backward transition
-        }
+      for (int i = 0; i < N; ++i) {
+        cxi[i * d + jc] = cx[i];
+        xi1[i * d + jc] = x1[i];        // STEP_FROM now remembers how to get back to t
+        cm[i * d + jc] = ms[i] + x1[i];  // solution at the checkpoint
+        m0[i * d + jc] = mt[i];         // INTERP_FROM <- filtering state at t
+        xi0[i * d + jc] = 0.0;          //   ... with an identity backward transition
       }
     }
     // checkpoint factor: qr_r([R1 G1^T ; RL1])
@@ -869,32 +851,28 @@ __global__ __launch_bounds__(256) void iso_interp_kernel(IsoView v, const Interp
 #pragma unroll
       for (int r = 0; r < N; ++r) Ts[r] = (l >= r) ? RL1[r] : 0.0;
       ln::qr_stack<N, false>(Ts, X, PT, PB, l);
-      ln::store_cols<N>(v.ck_fac + ck * N * N, Ts, lane);
+      ln::store_cols<N>(v.ck_fac + ck * N * N, Ts, l);
     }
     // checkpoint backward transition = merged (t0 -> t) transition
     ln::merge<N>(G0, RL0, Gt, RLt, l);
-    ln::store_rows<N>(v.ck_G + ck * N * N, Gt, lane);
-    ln::store_cols<N>(v.ck_Lam + ck * N * N, RLt, lane);
+    ln::store_rows<N>(v.ck_G + ck * N * N, Gt, l);
+    ln::store_cols<N>(v.ck_Lam + ck * N * N, RLt, l);
     // STEP_FROM transition <- (t1 -> t); INTERP_FROM <- (filter state at t, identity)
-    ln::store_rows<N>(v.cG + (size_t(arg.s1) * sB + b) * N * N, G1, lane);
-    ln::store_cols<N>(v.cLam + (size_t(arg.s1) * sB + b) * N * N, RL1, lane);
-    ln::store_cols<N>(v.fac + (size_t(arg.s0) * sB + b) * N * N, Rt, lane);
+    ln::store_rows<N>(v.cG + (size_t(arg.s1) * sB + b) * N * N, G1, l);
+    ln::store_cols<N>(v.cLam + (size_t(arg.s1) * sB + b) * N * N, RL1, l);
+    ln::store_cols<N>(v.fac + (size_t(arg.s0) * sB + b) * N * N, Rt, l);
     {
       double* g0 = v.cG + (size_t(arg.s0) * sB + b) * N * N;
       double* l0 = v.cLam + (size_t(arg.s0) * sB + b) * N * N;
-      if (lane < N) {
 #pragma unroll
-        for (int c = 0; c < N; ++c) {
-          g0[lane * N + c] = (lane == c) ? 1.0 : 0.0;
-          l0[lane * N + c] = 0.0;
-        }
+      for (int c = 0; c < N; ++c) {
+        g0[l * N + c] = (l == c) ? 1.0 : 0.0;
+        l0[l * N + c] = 0.0;
       }
     }
-    if (lane == 0) {
-      v.sigma[size_t(arg.s0) * sB + b] = sigma;
-      v.ck_steps[ck] = arg.steps;
-      v.ck_sigma[ck] = sigma;
-    }
+    v.sigma[size_t(arg.s0) * sB + b] = sigma;
+    v.ck_steps[ck] = arg.steps;
+    v.ck_sigma[ck] = sigma;
   }
 }
 
@@ -950,7 +928,7 @@ template <int N>
 __global__ __launch_bounds__(256) void iso_offgrid_kernel(IsoView v, const OffgridArg* __restrict__ qs, int Q,
                                                           const double* __restrict__ init, const double* __restrict__ smoothed,
                                                           const IwpConst* __restrict__ Kc, double* __restrict__ out) {
-  const int lane = threadIdx.x & 63, l = lane & 15;
+  const int lane = threadIdx.x & 63, l = ln::col_index<N>(lane);
   const int wv = threadIdx.x >> 6;
   const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv);
   if (item >= v.B * Q) return;
@@ -962,9 +940,11 @@ __global__ __launch_bounds__(256) void iso_offgrid_kernel(IsoView v, const Offgr
   const double* ms = smoothed + (size_t(b) * (v.K + 1) + c + 1) * N * d;  // smoothed mean at t_hi
   double* o = out + size_t(item) * N * d;
   if (a.at_grid) {
-    for (int j = lane; j < d; j += kWave)
-#pragma unroll
-      for (int i = 0; i < N; ++i) o[i * d + j] = ms[i * d + j];
+    const int nd = N * d;
+    for (int e0 = 0; e0 < nd; e0 += kWave) {
+      const int e = e0 + lane < nd ? e0 + lane : nd - 1;
+      o[e] = ms[e];
+    }
     return;
   }
   const double* m0 = (c == 0) ? init + size_t(b) * N * d : v.ck_mean + (size_t(b) * v.K + c - 1) * N * d;
@@ -1013,10 +993,8 @@ __global__ __launch_bounds__(256) void iso_offgrid_kernel(IsoView v, const Offgr
     }
     ln::opaque(G1);
     ln::matvec_rows<N, +1>(G1, diff, acc);
-    if (on) {
 #pragma unroll
-      for (int i = 0; i < N; ++i) o[i * d + j] = acc[i];
-    }
+    for (int i = 0; i < N; ++i) o[i * d + jc] = acc[i];
   }
 }
 

@@ -3,9 +3,9 @@
 // scratch from nu = 7 on -- and one of those spills, placed by the compiler in front of the exec restore of a `lane < d` region,
 // was the memory access fault of the looped smoother kernel).
 //
-// Layout: the lane index inside its 16-lane DPP row, l = lane & 15, is a matrix index; lanes l >= n hold zeros; the four DPP rows
-// of a wavefront hold four identical copies (everything is loaded with l, nothing is masked), so a row broadcast is a broadcast to
-// the whole wavefront.
+// Layout: l = min(lane & 15, n - 1) (col_index) is a matrix index: the lanes of a 16-lane DPP row beyond n mirror lane n - 1, and the
+// four DPP rows of a wavefront hold four identical copies, so a row broadcast is a broadcast to the whole wavefront, every lane
+// holds valid data, and a matrix is stored by ALL lanes without a predicate (the copies write the same value to the same address).
 //   "col-lane"  A[r] of lane l = element (r, l): lane l holds COLUMN l    (triangular factors: R, Lambda-factor)
 //   "row-lane"  A[c] of lane l = element (l, c): lane l holds ROW l       (backward gains G)
 // One matrix costs n doubles per lane. A uniform scalar is a register whose lanes agree; lane j's value becomes uniform by
@@ -13,8 +13,11 @@
 // hazard-checked by the compiler from __builtin_amdgcn_update_dpp).
 //
 // RULE: a DPP broadcast reads its source lane's register only when that lane is enabled. Every function here must be called with all 64
-// lanes enabled; the kernels keep every lane enabled throughout (indices are clamped, stores are predicated) instead of looping
-// over `lane < d`.
+// lanes enabled; the kernels keep every lane enabled throughout (indices are clamped, duplicate lanes repeat their neighbour's
+// work and its stores) instead of looping over `lane < d`: no exec-masked region is left in which the compiler could misplace a
+// spill or a copy.
+// The copies must stay IDENTICAL bit for bit: whatever enters the n x n algebra from the ODE dimensions (sums over the wavefront)
+// has to be the same in every lane (wave_sum of pnode_common.hpp; ln::uniform).
 //
 // Orthogonal triangularisations are Householder reflections (one reciprocal square root per COLUMN, the rotations of pnode_nxn.hpp
 // took one per ELEMENT), rows negated where needed so that the triangular factor has a non-negative diagonal like the one the
@@ -63,41 +66,38 @@ __device__ __forceinline__ double uniform(double x) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Loads / stores of row-major n x n matrices (leading dimension LD). Every lane loads (clamped index), lanes l >= N get zeros.
+// Loads / stores of row-major n x n matrices (leading dimension LD), l = col_index<N>(lane)
 // ---------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ int col_index(int lane) {
+  const int l = lane & 15;
+  return l < N ? l : N - 1;
+}
 template <int N, int LD = N>
 __device__ __forceinline__ void load_cols(const double* __restrict__ src, double (&A)[N], int l) {
-  const int lc = l < N ? l : N - 1;
 #pragma unroll
-  for (int r = 0; r < N; ++r) {
-    const double x = src[r * LD + lc];
-    A[r] = l < N ? x : 0.0;
-  }
+  for (int r = 0; r < N; ++r) A[r] = src[r * LD + l];
 }
 template <int N, int LD = N>
 __device__ __forceinline__ void load_rows(const double* __restrict__ src, double (&A)[N], int l) {
-  const int lc = l < N ? l : N - 1;
 #pragma unroll
-  for (int c = 0; c < N; ++c) {
-    const double x = src[lc * LD + c];
-    A[c] = l < N ? x : 0.0;
-  }
-}
-// `lane` = index in the wavefront (or team): the first N lanes write
-template <int N>
-__device__ __forceinline__ void store_cols(double* __restrict__ dst, const double (&A)[N], int lane) {
-  if (lane < N) {
-#pragma unroll
-    for (int r = 0; r < N; ++r) dst[r * N + lane] = A[r];
-  }
+  for (int c = 0; c < N; ++c) A[c] = src[l * LD + c];
 }
 template <int N>
-__device__ __forceinline__ void store_rows(double* __restrict__ dst, const double (&A)[N], int lane) {
-  if (lane < N) {
+__device__ __forceinline__ void store_cols(double* __restrict__ dst, const double (&A)[N], int l) {
 #pragma unroll
-    for (int c = 0; c < N; ++c) dst[lane * N + c] = A[c];
-  }
+  for (int r = 0; r < N; ++r) dst[r * N + l] = A[r];
 }
+template <int N>
+__device__ __forceinline__ void store_rows(double* __restrict__ dst, const double (&A)[N], int l) {
+#pragma unroll
+  for (int c = 0; c < N; ++c) dst[l * N + c] = A[c];
+}
+
+// Ties the order of two computations without an instruction: what is derived from `b` afterwards cannot be scheduled ahead of
+// `a`. Used between the rows of the small matrix products, whose n^2 independent broadcasts the scheduler would otherwise issue
+// up front and keep in registers.
+__device__ __forceinline__ void after(double& a, double& b) { asm volatile("" : "+v"(a), "+v"(b)); }
 
 // Inside a loop over the ODE dimensions: hides a loop-invariant matrix from the optimiser, which would otherwise hoist the n^2
 // row broadcasts of a matrix-vector product out of the loop and keep them all in registers (n = 9: 162 VGPRs per matrix --
@@ -106,15 +106,6 @@ template <int N>
 __device__ __forceinline__ void opaque(double (&A)[N]) {
 #pragma unroll
   for (int i = 0; i < N; ++i) asm volatile("" : "+v"(A[i]));
-}
-
-// my lane's entry of a uniform array
-template <int N>
-__device__ __forceinline__ double pick(const double (&u)[N], int l) {
-  double x = u[0];
-#pragma unroll
-  for (int i = 1; i < N; ++i) x = (l == i) ? u[i] : x;
-  return l < N ? x : 0.0;
 }
 
 // Per-lane constants of the prior: arow[k] = a[l][k] (row l of Abar), qcol[r] = qsT[r][l] (column l of chol(Qbar)^T).
@@ -212,6 +203,7 @@ __device__ __forceinline__ void time_update(const double (&arow)[N], const doubl
       acc += bcast<k>(Bm[c]) * arow[k];
     });
     M[c] = acc;
+    if (c + 1 < N) after(M[c], Bm[c + 1]);
   }
 #pragma unroll
   for (int r = 0; r < N; ++r) T[r] = sigma * qcol[r];
@@ -264,6 +256,7 @@ __device__ __forceinline__ void merge(const double (&G0)[N], const double (&RL0)
       acc += bcast<k>(RL[c]) * G0[k];
     });
     X[c] = acc;
+    if (c + 1 < N) after(X[c], RL[c + 1]);
   }
 #pragma unroll
   for (int r = 0; r < N; ++r) T[r] = (l >= r) ? RL0[r] : 0.0;
@@ -279,6 +272,7 @@ __device__ __forceinline__ void merge(const double (&G0)[N], const double (&RL0)
       acc += G0[k] * bcast<k>(G[j]);
     });
     Gn[j] = acc;
+    if (j + 1 < N) after(Gn[j], G[j + 1]);
   }
 #pragma unroll
   for (int j = 0; j < N; ++j) {
@@ -288,9 +282,9 @@ __device__ __forceinline__ void merge(const double (&G0)[N], const double (&RL0)
 }
 
 // y_i = sum_k A[i][k] x_k for a row-lane A and a per-lane vector x (x_k, y_i: one value per lane = per ODE dimension):
-// the entries of A become uniform by row broadcasts. `acc0` supplies the start values; `sign` = -1 subtracts.
+// the entries of A become uniform by row broadcasts. y supplies the start values; SIGN = -1 subtracts.
 template <int N, int SIGN>
-__device__ __forceinline__ void matvec_rows(const double (&A)[N], const double (&x)[N], double (&y)[N]) {
+__device__ __forceinline__ void matvec_rows(double (&A)[N], const double (&x)[N], double (&y)[N]) {
   sfor<0, N>([&](auto ic) PNODE_LAMBDA_INLINE {
     constexpr int i = decltype(ic)::value;
     double acc = y[i];
@@ -300,6 +294,8 @@ __device__ __forceinline__ void matvec_rows(const double (&A)[N], const double (
       acc = SIGN > 0 ? acc + a * x[k] : acc - a * x[k];
     }
     y[i] = acc;
+#pragma unroll
+    for (int k = 0; k < N; ++k) after(y[i], A[k]);  // (row by row: at most n broadcasts in flight)
   });
 }
 
