@@ -133,11 +133,50 @@ __device__ __forceinline__ void iso_store_regs(const IsoView& v, int b, int lane
   v.sigma[size_t(slot) * sB + b] = sigma;
 }
 
-// One attempted step from the state `s`. Returns the normalised error norm (a scalar the compiler knows to be uniform).
+// The running backward transition of the fixed-point smoother as register state: G (row-lane), RL (col-lane), xi (my ODE dimension)
 template <int N>
+__device__ __forceinline__ void iso_load_cond(const IsoView& v, int b, int lane, int slot, double (&G)[N], double (&RL)[N], double (&xi)[N]) {
+  const int d = v.d, l = ln::col_index<N>(lane);
+  const size_t sB = size_t(v.B);
+  ln::load_rows<N>(v.cG + (size_t(slot) * sB + b) * N * N, G, l);
+  ln::load_cols<N>(v.cLam + (size_t(slot) * sB + b) * N * N, RL, l);
+  const double* x = v.cxi + (size_t(slot) * sB + b) * N * d;
+  const int jc = lane < d ? lane : d - 1;
+#pragma unroll
+  for (int i = 0; i < N; ++i) xi[i] = x[i * d + jc];
+}
+template <int N>
+__device__ __forceinline__ void iso_store_cond(const IsoView& v, int b, int lane, int slot, const double (&G)[N], const double (&RL)[N],
+                                               const double (&xi)[N]) {
+  const int d = v.d, l = ln::col_index<N>(lane);
+  const size_t sB = size_t(v.B);
+  ln::store_rows<N>(v.cG + (size_t(slot) * sB + b) * N * N, G, l);
+  ln::store_cols<N>(v.cLam + (size_t(slot) * sB + b) * N * N, RL, l);
+  double* x = v.cxi + (size_t(slot) * sB + b) * N * d;
+  const int jc = lane < d ? lane : d - 1;
+#pragma unroll
+  for (int i = 0; i < N; ++i) x[i * d + jc] = xi[i];
+}
+template <int N>
+__device__ __forceinline__ void iso_copy_cond(double (&dG)[N], double (&dRL)[N], double (&dxi)[N], const double (&sG)[N], const double (&sRL)[N],
+                                              const double (&sxi)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    dG[i] = sG[i];
+    dRL[i] = sRL[i];
+    dxi[i] = sxi[i];
+  }
+}
+
+// One attempted step from the state `s`. Returns the normalised error norm (a scalar the compiler knows to be uniform).
+// FP: the fixed-point smoother's attempt -- also the backward transition of the step, composed with the running one
+// (sG0, sRL0, sxi0) into (oG, oRL, oxi); the factor comes out of the same reflections as in the filter.
+template <int N, bool FP = false>
 __device__ __forceinline__ double iso_attempt_regs(const IsoView& v, const IwpConst& K, const LanePrior<N>& P, int b, int lane, double dt,
                                                    double t, const double (&sm)[N], const double (&sR)[N], double ssigma, double (&om)[N],
-                                                   double (&oR)[N], double& osigma, double atol, double rtol, double* ybuf, double (&me)[N]) {
+                                                   double (&oR)[N], double& osigma, double atol, double rtol, double* ybuf, double (&me)[N],
+                                                   double (*sG0)[N] = nullptr, double (*sRL0)[N] = nullptr, const double (*sxi0)[N] = nullptr,
+                                                   double (*oG)[N] = nullptr, double (*oRL)[N] = nullptr, double (*oxi)[N] = nullptr) {
   const int d = v.d, k = v.k, l = ln::col_index<N>(lane);
   const bool on = lane < d;
   const int jc = on ? lane : d - 1;
@@ -184,9 +223,23 @@ __device__ __forceinline__ double iso_attempt_regs(const IsoView& v, const IwpCo
   const double err = dt * sigma_hat * s1;
   const double sigma = v.dynamic ? sigma_hat : ssigma;
 
-  // --- n x n square-root time update, correction on z = 0
-  double Gunused[N], RLunused[N];
-  ln::time_update<N, false>(P.arow, P.qcol, sR, pinv, pl, pil, sigma, l, oR, Gunused, RLunused);
+  // --- n x n square-root time update (+ backward transition), correction on z = 0
+  if constexpr (!FP) {
+    double Gunused[N], RLunused[N];
+    ln::time_update<N, false>(P.arow, P.qcol, sR, pinv, pl, pil, sigma, l, oR, Gunused, RLunused);
+  } else {
+    ln::time_update<N, true>(P.arow, P.qcol, sR, pinv, pl, pil, sigma, l, oR, *oG, *oRL);
+    // xi = m - G m^-, merged with the running backward transition
+    double xi[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      xi[i] = sm[i];
+      (*oxi)[i] = (*sxi0)[i];
+    }
+    ln::matvec_rows<N, -1>(*oG, me, xi);
+    ln::matvec_rows<N, +1>(*sG0, xi, *oxi);
+    ln::merge<N>(*sG0, *sRL0, *oG, *oRL, l);
+  }
   const double gain = correct_factor<N>(oR, k);
 
   // --- corrected mean + normalised error norm
@@ -205,20 +258,32 @@ __device__ __forceinline__ double iso_attempt_regs(const IsoView& v, const IwpCo
 // reads slot arg.src, writes slot arg.dst, returns the normalised error norm (team-uniform). `lane` is the
 // index inside the team (0 .. 64 W - 1); ybuf [k][d], zbuf [d], red [W] are the team's LDS scratch. Every wavefront of a team
 // carries the n x n algebra (identical copies); the first one writes it.
-template <int N, bool FP, int W>
+// REGS (W = 1, d <= 64; chosen by the launcher): one ODE dimension per lane, the register form above between a load and a store.
+template <int N, bool FP, int W, bool REGS>
 __device__ __forceinline__ double iso_attempt(const IsoView& v, const IwpConst& K, const LanePrior<N>& P, int b, int lane,
                                               const StepArg& arg, double* ybuf, double* zbuf, double* red) {
   constexpr int kTeam = kWave * W;
   const int wteam = lane >> 6, l = ln::col_index<N>(lane);
   const int d = v.d, k = v.k;
-  if constexpr (W == 1 && !FP) {
-    if (d <= kWave) {  // one ODE dimension per lane: the register form above
+  if constexpr (REGS) {
+    static_assert(W == 1, "register form: one wavefront per trajectory");
+    {
       double sm[N], sR[N], ssig, om[N], oR[N], osig;
       iso_load_regs<N>(v, b, lane, arg.src, sm, sR, ssig);
       double me[N];
-      const double e = iso_attempt_regs<N>(v, K, P, b, lane, arg.dt, arg.t, sm, sR, ssig, om, oR, osig, v.atol[b], v.rtol[b], ybuf, me);
-      iso_store_regs<N>(v, b, lane, arg.dst, om, oR, osig);
-      return e;
+      if constexpr (!FP) {
+        const double e = iso_attempt_regs<N>(v, K, P, b, lane, arg.dt, arg.t, sm, sR, ssig, om, oR, osig, v.atol[b], v.rtol[b], ybuf, me);
+        iso_store_regs<N>(v, b, lane, arg.dst, om, oR, osig);
+        return e;
+      } else {
+        double G0[N], RL0[N], xi0[N], oG[N], oRL[N], oxi[N];
+        iso_load_cond<N>(v, b, lane, arg.src, G0, RL0, xi0);
+        const double e = iso_attempt_regs<N, true>(v, K, P, b, lane, arg.dt, arg.t, sm, sR, ssig, om, oR, osig, v.atol[b], v.rtol[b], ybuf,
+                                                   me, &G0, &RL0, &xi0, &oG, &oRL, &oxi);
+        iso_store_regs<N>(v, b, lane, arg.dst, om, oR, osig);
+        iso_store_cond<N>(v, b, lane, arg.dst, oG, oRL, oxi);
+        return e;
+      }
     }
   }
 
@@ -348,7 +413,7 @@ __device__ __forceinline__ double iso_attempt(const IsoView& v, const IwpConst& 
   return ln::uniform(sqrt(acc2 / double(d)));
 }
 
-template <int N, bool FP, int W>
+template <int N, bool FP, int W, bool REGS>
 __global__ __launch_bounds__(256) void iso_step_kernel(IsoView v, const StepArg* __restrict__ args,
                                                        const IwpConst* __restrict__ Kc) {
   extern __shared__ double smem[];
@@ -364,7 +429,7 @@ __global__ __launch_bounds__(256) void iso_step_kernel(IsoView v, const StepArg*
   double* red = zbuf + v.d;                                           // [W]
   LanePrior<N> P;
   load_lane_prior<N>(Kc, P, ln::col_index<N>(lane));
-  const double e = iso_attempt<N, FP, W>(v, *Kc, P, b, lane, arg, ybuf, zbuf, red);
+  const double e = iso_attempt<N, FP, W, REGS>(v, *Kc, P, b, lane, arg, ybuf, zbuf, red);
   v.errnorm[b] = e;
 }
 
@@ -403,7 +468,7 @@ __device__ __forceinline__ bool iso_after_attempt(TrajCtl& c, const ControlParam
   return accept;
 }
 
-template <int N, bool FP, int W>
+template <int N, bool FP, int W, bool REGS>
 __global__ __launch_bounds__(256) void iso_advance_kernel(IsoView v, TrajCtl* __restrict__ ctl, const IwpConst* __restrict__ Kc,
                                                           ControlParams cp) {
   extern __shared__ double smem[];
@@ -421,10 +486,34 @@ __global__ __launch_bounds__(256) void iso_advance_kernel(IsoView v, TrajCtl* __
   load_lane_prior<N>(Kc, P, ln::col_index<N>(lane));
   int iters = 0;
   c.status = 0;
-  bool in_registers = false;
-  if constexpr (W == 1 && !FP) in_registers = v.d <= kWave;
-  if (in_registers) {
-    if constexpr (W == 1 && !FP) {
+  if constexpr (REGS) {
+    static_assert(W == 1, "register form: one wavefront per trajectory");
+    if constexpr (FP) {
+      // the smoother: the state AND the running backward transition stay in registers
+      const IwpConst& K = *Kc;
+      const double atol = v.atol[b], rtol = v.rtol[b];
+      double cm[N], cR[N], csig, cG[N], cRL[N], cxi[N];
+      iso_load_regs<N>(v, b, lane, c.s_sf, cm, cR, csig);
+      iso_load_cond<N>(v, b, lane, c.s_sf, cG, cRL, cxi);
+      while (c.t_sf + cp.numerical_zero < c.t_stop && iters < cp.max_iters) {
+        double dt = c.dt;
+        if (cp.clip) dt = fmin(dt, c.t_stop - c.t_sf);
+        double nm[N], nR[N], nsig, nG[N], nRL[N], nxi[N];
+        double me[N];
+        const double e = iso_attempt_regs<N, true>(v, K, P, b, lane, dt, c.t_sf, cm, cR, csig, nm, nR, nsig, atol, rtol, ybuf, me, &cG, &cRL,
+                                                   &cxi, &nG, &nRL, &nxi);
+        ++iters;
+        const int dst = c.s_pr;
+        if (iso_after_attempt(c, cp, e, dt)) {
+          iso_store_regs<N>(v, b, lane, dst, nm, nR, nsig);
+          iso_store_cond<N>(v, b, lane, dst, nG, nRL, nxi);
+          iso_copy_regs<N>(cm, cR, csig, nm, nR, nsig);
+          iso_copy_cond<N>(cG, cRL, cxi, nG, nRL, nxi);
+        }
+        if (c.status == 2) break;
+      }
+    }
+    if constexpr (!FP) {
       // the last accepted state stays in registers; a state goes to its slot when it is accepted (the slots STEP_FROM and
       // INTERP_FROM are what the host reads after the launch), a rejected attempt leaves no trace
       const IwpConst& K = *Kc;
@@ -452,7 +541,7 @@ __global__ __launch_bounds__(256) void iso_advance_kernel(IsoView v, TrajCtl* __
       if (cp.clip) dt = fmin(dt, c.t_stop - c.t_sf);
       StepArg arg;
       arg.dt = dt; arg.t = c.t_sf; arg.src = c.s_sf; arg.dst = c.s_pr; arg.active = 1; arg.pad = 0;
-      const double e = iso_attempt<N, FP, W>(v, *Kc, P, b, lane, arg, ybuf, zbuf, red);
+      const double e = iso_attempt<N, FP, W, false>(v, *Kc, P, b, lane, arg, ybuf, zbuf, red);
       if constexpr (W > 1) __syncthreads();
       __threadfence_block();  // the slot written by this attempt is read by the next one (other lanes of the team)
       ++iters;
@@ -1063,16 +1152,24 @@ template <int N>
 static void launch_step_n(const IsoView& v, const StepArg* args, const IwpConst* K, hipStream_t s) {
   if (iso_wide(v)) {
     if (v.fixedpoint)
-      hipLaunchKernelGGL((iso_step_kernel<N, true, 4>), dim3(v.B), dim3(256), iso_shm(v, 1), s, v, args, K);
+      hipLaunchKernelGGL((iso_step_kernel<N, true, 4, false>), dim3(v.B), dim3(256), iso_shm(v, 1), s, v, args, K);
     else
-      hipLaunchKernelGGL((iso_step_kernel<N, false, 4>), dim3(v.B), dim3(256), iso_shm(v, 1), s, v, args, K);
+      hipLaunchKernelGGL((iso_step_kernel<N, false, 4, false>), dim3(v.B), dim3(256), iso_shm(v, 1), s, v, args, K);
     return;
   }
   const int blocks = (v.B + 3) / 4;
-  if (v.fixedpoint)
-    hipLaunchKernelGGL((iso_step_kernel<N, true, 1>), dim3(blocks), dim3(256), iso_shm(v, 4), s, v, args, K);
-  else
-    hipLaunchKernelGGL((iso_step_kernel<N, false, 1>), dim3(blocks), dim3(256), iso_shm(v, 4), s, v, args, K);
+  const bool regs = v.d <= kWave;  // one ODE dimension per lane: the state of a trajectory in the registers of its wavefront
+  if (v.fixedpoint) {
+    if (regs)
+      hipLaunchKernelGGL((iso_step_kernel<N, true, 1, true>), dim3(blocks), dim3(256), iso_shm(v, 4), s, v, args, K);
+    else
+      hipLaunchKernelGGL((iso_step_kernel<N, true, 1, false>), dim3(blocks), dim3(256), iso_shm(v, 4), s, v, args, K);
+  } else {
+    if (regs)
+      hipLaunchKernelGGL((iso_step_kernel<N, false, 1, true>), dim3(blocks), dim3(256), iso_shm(v, 4), s, v, args, K);
+    else
+      hipLaunchKernelGGL((iso_step_kernel<N, false, 1, false>), dim3(blocks), dim3(256), iso_shm(v, 4), s, v, args, K);
+  }
 }
 template <int N>
 static void launch_interp_n(const IsoView& v, const InterpArg* args, const IwpConst* K, hipStream_t s) {
@@ -1110,9 +1207,9 @@ template <int N>
 static void launch_advance_n(const IsoView& v, TrajCtl* ctl, const IwpConst* K, const ControlParams& cp, hipStream_t s) {
   if (iso_wide(v)) {
     if (v.fixedpoint)
-      hipLaunchKernelGGL((iso_advance_kernel<N, true, 4>), dim3(v.B), dim3(256), iso_shm(v, 1), s, v, ctl, K, cp);
+      hipLaunchKernelGGL((iso_advance_kernel<N, true, 4, false>), dim3(v.B), dim3(256), iso_shm(v, 1), s, v, ctl, K, cp);
     else
-      hipLaunchKernelGGL((iso_advance_kernel<N, false, 4>), dim3(v.B), dim3(256), iso_shm(v, 1), s, v, ctl, K, cp);
+      hipLaunchKernelGGL((iso_advance_kernel<N, false, 4, false>), dim3(v.B), dim3(256), iso_shm(v, 1), s, v, ctl, K, cp);
     return;
   }
   const int blocks = (v.B + 3) / 4;
@@ -1126,10 +1223,18 @@ static void launch_advance_n(const IsoView& v, TrajCtl* ctl, const IwpConst* K, 
     hipLaunchKernelGGL((iso_advance_fp_kernel<N>), dim3(v.B), dim3(256), iso_fp_shm_doubles(N, v.k, v.d) * sizeof(double), s, v, ctl, K, cp);
     return;
   }
-  if (v.fixedpoint)
-    hipLaunchKernelGGL((iso_advance_kernel<N, true, 1>), dim3(blocks), dim3(256), iso_shm(v, 4), s, v, ctl, K, cp);
-  else
-    hipLaunchKernelGGL((iso_advance_kernel<N, false, 1>), dim3(blocks), dim3(256), iso_shm(v, 4), s, v, ctl, K, cp);
+  const bool regs = v.d <= kWave;
+  if (v.fixedpoint) {
+    if (regs)
+      hipLaunchKernelGGL((iso_advance_kernel<N, true, 1, true>), dim3(blocks), dim3(256), iso_shm(v, 4), s, v, ctl, K, cp);
+    else
+      hipLaunchKernelGGL((iso_advance_kernel<N, true, 1, false>), dim3(blocks), dim3(256), iso_shm(v, 4), s, v, ctl, K, cp);
+  } else {
+    if (regs)
+      hipLaunchKernelGGL((iso_advance_kernel<N, false, 1, true>), dim3(blocks), dim3(256), iso_shm(v, 4), s, v, ctl, K, cp);
+    else
+      hipLaunchKernelGGL((iso_advance_kernel<N, false, 1, false>), dim3(blocks), dim3(256), iso_shm(v, 4), s, v, ctl, K, cp);
+  }
 }
 // The device-resident controller serves every shape of the isotropic model (r03 refused the fixed-point smoother with nu >= 5
 // beyond d = 64: a work-around for the fault explained in DESIGN.md section 6b, gone with its cause).
