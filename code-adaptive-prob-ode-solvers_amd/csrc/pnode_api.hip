@@ -142,7 +142,7 @@ struct pnode_batch {
   std::vector<PhaseEvents> phase_pool;  // one set per round of pnode_advance_device, so that every attempt's phases are timed
   double phase_sum[4] = {0.0, 0.0, 0.0, 0.0};
   int64_t phase_count = 0;
-  const PhaseEvents* phase_last = nullptr;  // events of the most recent attempt (the handle's own set or one of the pool)
+  int phase_last = -1;  // events of the most recent attempt: index into phase_pool, -1 = the handle's own set (an index: the pool may grow)
   IsoView iso{};
   DenseView dn{};
   IwpConst* dK = nullptr;
@@ -563,7 +563,7 @@ static int advance_rounds_device(pnode_batch* h, TrajCtl* hCtl, const ControlPar
         HIP_TRY(hipEventElapsedTime(&ms, h->phase_pool[size_t(r)].ev[i], h->phase_pool[size_t(r)].ev[i + 1]));
         h->phase_sum[i] += ms;
       }
-    h->phase_last = &h->phase_pool[size_t(rounds - 1)];  // pnode_last_phase_ms keeps meaning "the last attempt"
+    h->phase_last = rounds - 1;  // pnode_last_phase_ms keeps meaning "the last attempt"
   }
   return check_fault(h);
 }
@@ -588,7 +588,7 @@ int pnode_attempt_step(pnode_batch* h, const double* dt, const uint8_t* active, 
   // zero-copy hand-over: the kernels read StepArg[B] from and write err_norm[B] to pinned host memory, so a step
   // costs the launches plus one stream synchronisation (no hipMemcpy calls on the critical path)
   if (h->step_timing) HIP_TRY(hipEventRecord(h->ev0, h->stream));
-  h->phase_last = nullptr;
+  h->phase_last = -1;
   enqueue_step(h, h->zArgs);
   if (h->dense && h->dn.fixedpoint) {
     for (size_t b = 0; b < B; ++b) {
@@ -844,8 +844,6 @@ int pnode_solve_adaptive_save_at_device(pnode_batch* h, const double* save_at, i
   // dense model beyond the fused one-wavefront kernel: multi-kernel form (controller kernel between the attempts), filter only
   const bool multi = h->dense && !(dense_small_supported(h->dn) && !h->dn.force_generic);
   if (h->cfg.vf_id == PNODE_VF_USER) return fail(PNODE_EINVAL, "the device-resident controller needs a built-in vector field");
-  if (!h->dense && !iso_advance_supported(h->iso))
-    return fail(PNODE_EINVAL, "device-resident controller: the isotropic fixed-point smoother with nu >= 5 is served for d <= 64; use the host controller");
   HIP_TRY(hipSetDevice(h->cfg.device));
   const size_t B = h->cfg.batch;
   const int K = num_save - 1;
@@ -1327,7 +1325,7 @@ int pnode_set_phase_timing(pnode_batch* h, int32_t enabled) {
 int pnode_last_phase_ms(pnode_batch* h, float* ms_out) {
   if (!h || !ms_out) return fail(PNODE_EINVAL, "null argument");
   if (!h->dense || !h->phase_timing) return fail(PNODE_ESTATE, "phase timing is available for the dense model after set_phase_timing(1)");
-  const PhaseEvents& pe = h->phase_last ? *h->phase_last : h->phase;
+  const PhaseEvents& pe = h->phase_last >= 0 && size_t(h->phase_last) < h->phase_pool.size() ? h->phase_pool[size_t(h->phase_last)] : h->phase;
   for (int i = 0; i < 4; ++i) HIP_TRY(hipEventElapsedTime(ms_out + i, pe.ev[i], pe.ev[i + 1]));
   return PNODE_OK;
 }

@@ -1236,10 +1236,6 @@ static void launch_advance_n(const IsoView& v, TrajCtl* ctl, const IwpConst* K, 
       hipLaunchKernelGGL((iso_advance_kernel<N, false, 1, false>), dim3(blocks), dim3(256), iso_shm(v, 4), s, v, ctl, K, cp);
   }
 }
-// The device-resident controller serves every shape of the isotropic model (r03 refused the fixed-point smoother with nu >= 5
-// beyond d = 64: a work-around for the fault explained in DESIGN.md section 6b, gone with its cause).
-bool iso_advance_supported(const IsoView&) { return true; }
-
 void iso_launch_advance(const IsoView& v, TrajCtl* ctl, const IwpConst* K, const ControlParams& cp, hipStream_t s) {
 #define CALL(NN) launch_advance_n<NN>(v, ctl, K, cp, s)
   PNODE_DISPATCH_N(v.n, CALL)

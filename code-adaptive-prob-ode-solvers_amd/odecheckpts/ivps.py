@@ -1,10 +1,10 @@
 """Initial value problems of the reference zoo that the hot path covers.
 
 Counterparts of /root/reference/src/odecheckpts/ivps.py: brusselator (:124-156), van_der_pol (:159-167),
-rigid_body (:20-29), pleiades_1st / pleiades_2nd (:44-99), logistic (:8-17). Each returns
-`(vf, u0, time_span, params)` like the reference, with `vf` a device-backed VectorField that is also
-callable on NumPy arrays as `vf(*u, t=..., p=...)`. Problems outside the benchmark configurations
-(three_body_restricted, neural_ode_mlp) are not provided.
+rigid_body (:20-29), pleiades_1st / pleiades_2nd (:44-99), logistic (:8-17), three_body_restricted (:32-41; the
+reference's experiment 5). Each returns what the reference's function returns, with `vf` a device-backed VectorField that
+is also callable on NumPy arrays as `vf(*u, t=..., p=...)`. `neural_ode_mlp` (a training loop's model)
+is outside the hot path and raises.
 """
 
 from __future__ import annotations

@@ -229,9 +229,9 @@ int pnode_set_generic_path(pnode_batch* h, int32_t enabled);
  * one trajectory is 1.6x shorter: single trajectories, tolerance sweeps, anything bound by its slowest member). Both kernels
  * evaluate the same expressions in the same order: the controller's decisions (accepted steps, step sizes) are identical bit for
  * bit, the smoothed means agree to rounding (1e-13 relative: multiply-adds of the backward transitions are contracted differently
- * by the compiler) -- hence a per-handle choice of the caller, never one the library makes from the batch size. From nu = 5 on
- * kernel 1 serves both settings (d <= 64); pnode_solve_adaptive_save_at_device returns PNODE_EINVAL for nu >= 5 with d > 64
- * (use the host controller). */
+ * by the compiler) -- hence a per-handle choice of the caller, never one the library makes from the batch size. Both kernels
+ * exist for every nu <= 8; beyond d = 64 the setting is ignored (one wavefront, or one workgroup for d > 128, loops over the
+ * ODE dimensions). */
 int pnode_set_smoother_pipeline(pnode_batch* h, int32_t mode);
 /* Diagnostics of the one-launch LQ of the dense MFMA path (csrc/pnode_dense_lq4.hip): its wavefronts hand panels over through
  * flag words in LDS, and every wait is a bounded spin. A wait that runs into its bound is reported by the call that synchronises
