@@ -145,6 +145,12 @@ __device__ __forceinline__ void preconditioner(double dt, const IwpConst& K, dou
   }
 }
 
+// A sum of squares that has overflowed must not vanish from the result: finite / inf = 0 would silently switch a measurement
+// update off (r04: on the reference's too-coarse Van der Pol grid, experiments/1_van_der_pol/vdp.py:94-108, the innovation
+// variance overflowed at |u| ~ 1e54, the gain became 0, and the solution crept on, finite, to 1e61 -- where the reference, the
+// oracle and exact arithmetic (tests/test_oracle_golden.py) all blow up). +-inf becomes NaN, everything else passes.
+__device__ __forceinline__ double overflow_to_nan(double x) { return (fabs(x) <= 1.7976931348623157e308) ? x : __builtin_nan(""); }
+
 // 1/sqrt(x) and 1/x to full fp64 precision from the hardware estimates + Newton steps: short dependency chains
 // instead of the ~30-instruction IEEE sqrt / divide expansions (the small-matrix algebra is latency-bound).
 __device__ __forceinline__ double fast_rsqrt(double x) {

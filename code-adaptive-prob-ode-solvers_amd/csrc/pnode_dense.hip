@@ -40,7 +40,7 @@ __device__ __forceinline__ void preconditioner_rt(int n, double dt, const IwpCon
 __device__ void wg_cholesky(double* A, int d, int ld) {
   for (int c = 0; c < d; ++c) {
     __syncthreads();
-    const double piv = sqrt(A[c * ld + c]);
+    const double piv = sqrt(overflow_to_nan(A[c * ld + c]));
     __syncthreads();
     if (threadIdx.x == 0) A[c * ld + c] = piv;
     for (int r = c + 1 + threadIdx.x; r < d; r += kThreads) A[r * ld + c] /= piv;

@@ -101,7 +101,7 @@ __device__ __forceinline__ double dense_d1_core(const DenseView& v, const IwpCon
     for (int i = c; i < N; ++i) b0 += K.qsT[c][i] * (p[i] * h[i]);
     s1sq += b0 * b0;
   }
-  const double s1 = sqrt(s1sq);
+  const double s1 = sqrt(overflow_to_nan(s1sq));
   const double sigma_hat = fabs(z) / s1;
   const double err = dt * sigma_hat * s1;
   const double sigma = v.dynamic ? sigma_hat : sigma_prev;
@@ -123,7 +123,7 @@ __device__ __forceinline__ double dense_d1_core(const DenseView& v, const IwpCon
     double acc = 0.0;
 #pragma unroll
     for (int c = 0; c < N; ++c) acc += Rm[c][i] * F[c];
-    gain[i] = acc / s2;
+    gain[i] = acc / overflow_to_nan(s2);
   }
 #pragma unroll
   for (int i = 0; i < N; ++i) mnew[i] = me[i] - gain[i] * z;
@@ -257,7 +257,7 @@ __device__ double dense_small_attempt(const DenseView& v, const IwpConst& K, int
   wsync();
   // Cholesky of S1 (lower, in place) + forward solve of z; lane r owns row r
   for (int c = 0; c < d; ++c) {
-    const double piv = sqrt(s.S[c * LS + c]);
+    const double piv = sqrt(overflow_to_nan(s.S[c * LS + c]));
     wsync();
     for (int r = c + lane; r < d; r += kWave) s.S[r * LS + c] = (r == c) ? piv : s.S[r * LS + c] / piv;
     wsync();
@@ -336,7 +336,7 @@ __device__ double dense_small_attempt(const DenseView& v, const IwpConst& K, int
   for (int j = lane; j < d; j += kWave) s.wz[j] = s.z[j];
   wsync();
   for (int c = 0; c < d; ++c) {
-    const double piv = sqrt(s.S[c * LS + c]);
+    const double piv = sqrt(overflow_to_nan(s.S[c * LS + c]));
     wsync();
     for (int r = c + lane; r < d; r += kWave) s.S[r * LS + c] = (r == c) ? piv : s.S[r * LS + c] / piv;
     wsync();

@@ -83,7 +83,7 @@ __device__ __forceinline__ double correct_factor(double (&Rm)[N], int k) {
   double acc = 0.0;
 #pragma unroll
   for (int c = 0; c < N; ++c) acc += Rm[c] * F[c];
-  const double gain = acc / s2;
+  const double gain = acc / overflow_to_nan(s2);
 #pragma unroll
   for (int c = 0; c < N; ++c) Rm[c] -= F[c] * gain;
   return gain;

@@ -1,5 +1,7 @@
 """The CPU oracle (oracle/pn_oracle.py) against the reference's committed outputs (tests/golden/)."""
 
+import math
+
 import numpy as np
 import pn_oracle as po
 import pytest
@@ -188,3 +190,52 @@ def test_three_body_step_counts_of_experiment_5(golden, k):
     vf, cfg, tc, t0, t1 = _three_body_setup(4)
     sol = po.solve_adaptive_save_every_step(cfg, po.AdaptiveConfig(tol, tol), oracle_problem(vf), po.initial_state(cfg, tc, t0), t1, 0.01)
     assert len(sol.t) - 1 == want
+
+
+def test_vdp_coarse_grid_leaves_the_fp64_range_in_exact_arithmetic(golden):
+    """The reference asserts NaNs on its too-coarse equidistant grid (experiments/1_van_der_pol/vdp.py:94-97, 107-108). Is that an
+    accident of its rounding path, or the algorithm? The dense EKF1 of that run (d = 1, nu = 4, dynamic calibration) restated
+    in covariance form -- equivalent to the square-root form when nothing is rounded -- and run with mpmath at 40 digits over the
+    first 800 points of the committed grid: the state leaves the limit cycle around step 380 and grows super-exponentially,
+    |m| > 1e140 and sigma^2 > 1e290 at step 750 (30, 80 and 200 digits agree on the magnitudes, not on the digits: the orbit is
+    chaotic, the blow-up is not). No fp64 evaluation of this solver on this grid can stay finite much beyond step 1200, where |u|
+    itself passes 1e308; a finite result is not a legitimate rounding path. The HIP path asserts NaNs like the reference
+    (test_gpu_parity.py::test_vdp_golden_prefix_through_api)."""
+    mpmath = pytest.importorskip("mpmath")
+    mp, mpf, matrix = mpmath.mp, mpmath.mpf, mpmath.matrix
+    mp.dps = 40
+    grid = golden["vdp"]["grid_fixed_inaccurate"]
+    nu, n, mu = 4, 5, mpf(1000)
+    A, Qb = matrix(n, n), matrix(n, n)
+    for i in range(n):
+        for j in range(n):
+            if j >= i:
+                A[i, j] = mpf(math.comb(nu - i, nu - j))
+            Qb[i, j] = mpf(1) / (2 * nu + 1 - i - j)
+    vf = lambda u, du: mu * (du * (1 - u * u) - u)  # noqa: E731
+    tc = po.taylor_coefficients(lambda u, du: 1000.0 * (du * (1.0 - u * u) - u), [np.array([2.0]), np.array([0.0])], 3)
+    m = matrix([mpf(float(c[0])) for c in tc])
+    S = matrix(n, n)
+    seen = {}
+    for s in range(1, 801):
+        dt = mpf(float(grid[s])) - mpf(float(grid[s - 1]))
+        P, Pi = matrix(n, n), matrix(n, n)
+        for i in range(n):
+            P[i, i] = dt ** (mpf(nu - i) + mpf(1) / 2) / math.factorial(nu - i)
+            Pi[i, i] = 1 / P[i, i]
+        At, Qu = P * A * Pi, P * Qb * P
+        me = At * m
+        u, du = me[0], me[1]
+        z = me[2] - vf(u, du)
+        H = matrix(1, n)
+        H[0, 0], H[0, 1], H[0, 2] = -mu * (-2 * u * du - 1), -mu * (1 - u * u), 1
+        sig2 = z * z / (H * Qu * H.T)[0, 0]
+        Sm = At * S * At.T + sig2 * Qu
+        Sz = (H * Sm * H.T)[0, 0]
+        K = Sm * H.T / Sz
+        m, S = me - K * z, Sm - K * Sz * K.T
+        if s in (250, 500, 750):
+            seen[s] = (max(abs(m[i]) for i in range(n)), sig2)
+    assert seen[250][0] < 1e3                              # still on the limit cycle (the oracle and the HIP path agree to 1e-7 here)
+    assert seen[500][0] > mpf(10) ** 40                    # left it
+    assert seen[750][0] > mpf(10) ** 140 and seen[750][1] > mpf(10) ** 290
