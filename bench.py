@@ -41,7 +41,7 @@ TOL = 1e-6
 DT0 = 0.01
 FP64_PEAK_TFLOPS = 78.6  # MI355X fp64 vector = matrix peak
 HBM_PEAK_GBS = 8000.0
-PMC_SUMMARIES = ("r03_pmc_summary.json", "r02_pmc_summary.json")  # newest committed rocprofv3 --pmc summary first
+PMC_SUMMARIES = ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json")  # newest committed rocprofv3 --pmc summary first
 
 
 def problem_batch(B, offset=0, total=None):
@@ -65,10 +65,27 @@ def algorithmic_flops_lq(D, d):
     return 2.0 * D * D * (D - d)
 
 
+def _library_has_kernel(base_name):
+    """Whether the built library contains a kernel of this (unmangled, template arguments stripped) name: the code object is
+    embedded in the .so, the mangled kernel names contain the plain identifier."""
+    global _LIB_BYTES
+    if _LIB_BYTES is None:
+        try:
+            _LIB_BYTES = open(os.path.join(ROOT, "code-adaptive-prob-ode-solvers_amd", "csrc", "libpnode_hip.so"), "rb").read()
+        except OSError:
+            _LIB_BYTES = b""
+    return base_name.encode() in _LIB_BYTES
+
+
+_LIB_BYTES = None
+
+
 def measured_traffic(kernel_prefix, batch):
-    """HBM bytes per launch of the dominant kernel from the committed PMC summary
-    (profiles/r03_pmc_summary.json, produced on an MI355X by scripts/collect_profile.sh with separate
-    --pmc passes; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md), scaled to this batch."""
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC summary
+    (profiles/rNN_pmc_summary.json, produced on an MI355X by scripts/collect_profile.sh with separate
+    --pmc passes; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md), scaled to this batch.
+    A summary is REFUSED (None) when one of the kernels it names is not in the built library: the profile then belongs to
+    another version of the kernels and its traffic says nothing about this run."""
     data = None
     for name in PMC_SUMMARIES:
         try:
@@ -77,6 +94,10 @@ def measured_traffic(kernel_prefix, batch):
         except OSError:
             continue
     if data is None:
+        return None
+    stale = sorted({k.split("<")[0] for k in data if "hbm_bytes_per_launch" in data[k] and not _library_has_kernel(k.split("<")[0].split("::")[-1])})
+    if stale:
+        print(f"bench.py: profile names kernels the library does not contain ({', '.join(stale)}): traffic not reported", file=sys.stderr)
         return None
     total = 0.0
     for name, v in data.items():  # the LQ runs as two launches (first pass + remaining passes): sum them
@@ -167,7 +188,7 @@ def cpu_baseline(seconds=5.0, repeats=2):
             "sample": f"NumPy oracle (oracle/pn_oracle.py), 1 trajectory, {accepted} accepted steps in {el:.1f}s"}
 
 
-def solve_on_handle(B, device_controller, device, repeats=3):
+def solve_on_handle(B, device_controller, device, repeats=3, t1=10.0):
     """The isotropic whole solve on an EXISTING handle (C-ABI calls of ivpsolve.solve_adaptive_save_at: pnode_set_initial,
     pnode_set_tolerances, the native driver, the read-back), fastest of `repeats`: creating a handle (device and pinned-host
     allocations) takes 5 to 40 ms depending on the box, more than the 25 ms solve it would be timed with."""
@@ -179,7 +200,7 @@ def solve_on_handle(B, device_controller, device, repeats=3):
     solver = ivpsolvers.solver_dynamic(ivpsolvers.strategy_filter(ivpsolvers.prior_ibm(NU), ivpsolvers.correction_ts0()))
     asolver = ivpsolve.adaptive(solver, atol=TOL, rtol=TOL)
     init = solver.initial_condition(tcs, 1.0)
-    save_at = np.linspace(0.0, 10.0, 5)
+    save_at = np.linspace(0.0, t1, 5)
     batch = ivpsolve._make_batch(vf, init, solver, len(save_at) - 1, device)
     best = None
     for _ in range(repeats):
@@ -255,8 +276,22 @@ def extras(args, batch, loop, active, dense, device_ctl, device):
                 r["moved_bytes_per_accepted_step"] = byts // 2
                 r["us_per_attempt_of_a_trajectory"] = r["seconds"] / (r["attempted"] / B) * 1e6
             iso[name] = r
+        # the ceiling with the machine FILLED (1024 trajectories put one wavefront on each of the 1024 SIMDs): the same solve with
+        # 8 and 64 wavefronts per SIMD's worth of trajectories, device controller; fraction of the HBM roofline on the bytes the
+        # kernel actually moves (the accepted states: mean, factor, output scale)
+        filled = {}
+        moved = 8 * (n * d + n * n + 1)
+        for Bf in (8192, 65536):
+            r = solve_on_handle(Bf, True, device, repeats=2)
+            r["moved_bytes_per_accepted_step"] = moved
+            r["hbm_GBps_moved"] = r["accepted"] / r["seconds"] * moved / 1e9
+            r["hbm_frac_moved"] = r["hbm_GBps_moved"] / HBM_PEAK_GBS
+            r["hbm_frac_survey_formula"] = r["attempted"] / r["seconds"] * byts / 1e9 / HBM_PEAK_GBS
+            r["us_per_attempt_of_a_trajectory"] = r["seconds"] / (r["attempted"] / Bf) * 1e6
+            filled[f"batch_{Bf}"] = r
         out["isotropic_ekf0_nu3"] = {"workload": f"Brusselator N=32 (d=64), nu=3, isotropic EKF0 (the reference's own model for this PDE), "
-                                                 f"filter, dynamic, tol 1e-6, batch {B}, whole solve t in [0, 10]", **iso}
+                                                 f"filter, dynamic, tol 1e-6, batch {B}, whole solve t in [0, 10]", **iso,
+                                     "machine_filled": filled}
     return out
 
 

@@ -147,6 +147,9 @@ struct pnode_batch {
   DenseView dn{};
   IwpConst* dK = nullptr;
   TrajCtl* dCtl = nullptr;      // device-resident controller state (multi-kernel form)
+  double* dPlanSave = nullptr;  // isotropic model, checkpoints inside the controller kernel (CkptPlan): save_at [B][K + 1],
+  int32_t* dPlanCur = nullptr;  //   cursor [B],
+  int64_t* dPlanNum = nullptr;  //   accepted steps at the checkpoints [B][K + 1]
   FpArg* dFp = nullptr;         // arguments of the backward-transition kernels in that form (dense fixed-point smoother)
   StepArg* dArgs = nullptr;
   InterpArg* dIargs = nullptr;
@@ -292,6 +295,11 @@ int pnode_create(const pnode_config* cfg, pnode_batch** out) {
   ALLOC(h->dK, 1);
   ALLOC(h->dArgs, B);
   ALLOC(h->dCtl, B);
+  if (cfg->model == PNODE_MODEL_ISOTROPIC) {
+    ALLOC(h->dPlanSave, B * (size_t(cfg->num_checkpoints) + 1));
+    ALLOC(h->dPlanCur, B);
+    ALLOC(h->dPlanNum, B * (size_t(cfg->num_checkpoints) + 1));
+  }
   ALLOC(h->dFp, B);
   ALLOC(h->dIargs, B);
   ALLOC(h->dFilled, B);
@@ -872,6 +880,70 @@ int pnode_solve_adaptive_save_at_device(pnode_batch* h, const double* save_at, i
   for (size_t b = 0; b < B; ++b) {
     failed_out[b] = 0;
     for (int i = 0; i < num_save; ++i) num_steps_out[b * num_save + i] = 0;
+  }
+  if (!h->dense && iso_advance_walks_checkpoints(h->iso)) {
+    // Isotropic model: the launch walks over the save_at points itself (interpolation / right corner inside the controller kernel);
+    // the host only relaunches trajectories whose iteration budget ran out. One synchronisation per launch.
+    double* dSave = h->dPlanSave;  // (allocated with the handle for its checkpoint capacity: num_save - 1 <= num_checkpoints)
+    int32_t* dCur = h->dPlanCur;
+    int64_t* dNum = h->dPlanNum;
+    const size_t nsave = per_traj ? B * size_t(num_save) : size_t(num_save);
+    auto release = [&] { (void)hipHostFree(hCtl); };
+    std::vector<int32_t> cur(B, 1);
+    std::vector<int64_t> num(B * size_t(num_save), 0);
+    hipError_t e = hipMemcpyAsync(dSave, save_at, nsave * sizeof(double), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dCur, cur.data(), B * sizeof(int32_t), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dNum, num.data(), B * size_t(num_save) * sizeof(int64_t), hipMemcpyHostToDevice, h->stream);
+    if (e != hipSuccess) {
+      release();
+      return fail(PNODE_EDEVICE, hipGetErrorString(e));
+    }
+    for (size_t b = 0; b < B; ++b) {
+      TrajCtl& c = hCtl[b];
+      c.status = 0;
+      c.t_sf = h->t_sf[b]; c.t_if = h->t_if[b]; c.dt = dt[b]; c.log_prev = 0.0; c.t_stop = sa(b, 1);
+      c.steps = h->steps[b]; c.attempts = 0;
+      c.s_sf = h->s_sf[b]; c.s_if = h->s_if[b]; c.s_pr = h->s_pr[b];
+    }
+    const CkptPlan plan{dSave, per_traj ? 1 : 0, K, dCur, dNum};
+    int rc2 = PNODE_OK;
+    for (;;) {
+      iso_launch_advance(h->iso, zCtl, h->dK, cp, h->stream, plan);
+      e = hipGetLastError();
+      if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+      if (e != hipSuccess) {
+        rc2 = fail(PNODE_EDEVICE, hipGetErrorString(e));
+        break;
+      }
+      rc2 = check_fault(h);
+      if (rc2 != PNODE_OK) break;
+      bool again = false;
+      for (size_t b = 0; b < B; ++b) {
+        TrajCtl& c = hCtl[b];
+        if (c.status < 0) continue;
+        if (c.status == 3) {  // iteration budget spent: goes on in the next launch
+          c.status = 0;
+          again = true;
+          continue;
+        }
+        if (c.status == 2) failed_out[b] = 1;
+        h->t_sf[b] = c.t_sf; h->t_if[b] = c.t_if; h->steps[b] = c.steps;
+        h->s_sf[b] = int8_t(c.s_sf); h->s_if[b] = int8_t(c.s_if); h->s_pr[b] = int8_t(c.s_pr);
+        h->pending[b] = 0;
+        num_attempts_out[b] = c.attempts;
+        c.status = -1;  // done (every checkpoint stored) or failed
+      }
+      if (!again) break;
+    }
+    if (rc2 == PNODE_OK) {
+      e = hipMemcpy(num.data(), dNum, B * size_t(num_save) * sizeof(int64_t), hipMemcpyDeviceToHost);
+      if (e != hipSuccess) rc2 = fail(PNODE_EDEVICE, hipGetErrorString(e));
+    }
+    release();
+    if (rc2 != PNODE_OK) return rc2;
+    for (size_t i = 0; i < B * size_t(num_save); ++i) num_steps_out[i] = num[i];
+    h->stepped = true;
+    return PNODE_OK;
   }
   int rc = PNODE_OK;
   for (;;) {

@@ -60,6 +60,15 @@ struct ControlParams {
   double safety, factor_min, factor_max, n1, n2, numerical_zero;
   int32_t clip, max_iters;
 };
+// The save_at points handed to the device-resident controller of the isotropic model: the launch then walks over them itself
+// (interpolation / right corner of every checkpoint its trajectory passes, /root/reference/src/odecheckpts/ivpsolvers.py:71-77)
+// and ends when the last one is stored, a trajectory has failed or the iteration budget is spent.
+struct CkptPlan {
+  const double* save_at;  // device: [K + 1] shared or [B][K + 1]; nullptr: the launch ends at TrajCtl::t_stop, the host does the checkpoint
+  int32_t per_traj, K;
+  int32_t* cursor;        // device [B]: index of the next save_at point (1 .. K + 1), in / out
+  int64_t* num_steps;     // device [B][K + 1]: accepted steps when the checkpoint was stored
+};
 
 // One controller decision of a trajectory between two attempts of the multi-kernel dense paths (dense_ctl_kernel, and the tail of
 // the fused measurement-update kernel): takes the error norm of the attempt just made (unless `first`), accepts / rejects,

@@ -38,7 +38,9 @@ struct DenseView;
 bool dense_d1_fixed_grid_supported(const DenseView& v);
 void dense_d1_launch_fixed_grid(const DenseView& v, const StepArg* args, const IwpConst* K, double* out, int G, hipStream_t s);
 void iso_launch_interp(const IsoView& v, const InterpArg* args, const IwpConst* K, hipStream_t s);
-void iso_launch_advance(const IsoView& v, TrajCtl* ctl, const IwpConst* K, const ControlParams& cp, hipStream_t s);
+void iso_launch_advance(const IsoView& v, TrajCtl* ctl, const IwpConst* K, const ControlParams& cp, hipStream_t s,
+                        const CkptPlan& plan = CkptPlan{nullptr, 0, 0, nullptr, nullptr});
+bool iso_advance_walks_checkpoints(const IsoView& v);  // the kernel that would run takes a CkptPlan (all but the pipelined smoother kernel)
 void iso_launch_smooth(const IsoView& v, const int32_t* num_filled, double* out, hipStream_t s);
 void iso_launch_offgrid(const IsoView& v, const OffgridArg* qs, int Q, const double* init, const double* smoothed, const IwpConst* K,
                         double* out, hipStream_t s);

@@ -38,6 +38,13 @@ __device__ __forceinline__ double team_sum(double v, double* red, int wteam) {
   return t;
 }
 
+// A wave-uniform value that this kernel itself may have written a moment ago (the output scale of a slot): loaded through the VECTOR
+// memory path -- the scalar data cache is not coherent with the wavefront's own vector stores.
+__device__ __forceinline__ double load_written(const double* p) {
+  asm volatile("" : "+v"(p));
+  return ln::uniform(*p);
+}
+
 // Per-lane constants of a kernel: row l of Abar, column l of chol(Qbar)^T, (nu - l)!  (l = ln::col_index<N>(lane))
 template <int N>
 struct LanePrior {
@@ -117,7 +124,7 @@ __device__ __forceinline__ void iso_load_regs(const IsoView& v, int b, int lane,
 #pragma unroll
   for (int i = 0; i < N; ++i) m[i] = msrc[i * d + jc];
   ln::load_cols<N>(v.fac + (size_t(slot) * sB + b) * N * N, R, ln::col_index<N>(lane));
-  sigma = v.sigma[size_t(slot) * sB + b];
+  sigma = load_written(v.sigma + size_t(slot) * sB + b);
 }
 
 template <int N>
@@ -343,7 +350,7 @@ __device__ __forceinline__ double iso_attempt(const IsoView& v, const IwpConst& 
   const double s1 = pk * K.qdiag_sqrt[k];
   const double sigma_hat = sqrt(zz) / (s1 * sqrt(double(d)));
   const double err = dt * sigma_hat * s1;
-  const double sigma_prev = v.sigma[size_t(arg.src) * sB + b];
+  const double sigma_prev = load_written(v.sigma + size_t(arg.src) * sB + b);
   const double sigma = v.dynamic ? sigma_hat : sigma_prev;
 
   // --- n x n square-root time update (+ backward transition for the fixed-point smoother)
@@ -433,6 +440,211 @@ __global__ __launch_bounds__(256) void iso_step_kernel(IsoView v, const StepArg*
   v.errnorm[b] = e;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Checkpoint interpolation (probdiffeq "interpolate" for filter / fixedpoint) and right corner
+// ---------------------------------------------------------------------------------------------
+
+// One checkpoint of trajectory b by ONE wavefront (lane = 0 .. 63, every lane enabled): the body of iso_interp_kernel, also called
+// by the device-resident controller when it walks over the save_at points itself (iso_advance_kernel with a CkptPlan).
+template <int N, bool FP>
+__device__ __forceinline__ void iso_interp_body(const IsoView& v, const IwpConst* __restrict__ Kc, int b, int lane, const InterpArg& arg) {
+  const int l = ln::col_index<N>(lane);
+  const IwpConst& K = *Kc;
+  const int d = v.d;
+  const size_t sB = size_t(v.B);
+  const size_t ck = size_t(b) * v.K + arg.ckpt;
+  double* m0 = v.mean + (size_t(arg.s0) * sB + b) * N * d;
+  double* m1 = v.mean + (size_t(arg.s1) * sB + b) * N * d;
+  double* cm = v.ck_mean + ck * N * d;
+
+  if (arg.at_step) {
+    // checkpoint coincides with STEP_FROM: store it; fixedpoint resets the backward transition
+    // (wave-uniform trip counts, clamped indices, unpredicated stores: the duplicate lanes repeat their neighbour's copy)
+    const int nd = N * d;
+    for (int e0 = 0; e0 < nd; e0 += kWave) {
+      const int e = e0 + lane < nd ? e0 + lane : nd - 1;
+      cm[e] = m1[e];
+    }
+    const double* f1 = v.fac + (size_t(arg.s1) * sB + b) * N * N;
+    for (int e0 = 0; e0 < N * N; e0 += kWave) {
+      const int e = e0 + lane < N * N ? e0 + lane : N * N - 1;
+      v.ck_fac[ck * N * N + e] = f1[e];
+    }
+    if constexpr (FP) {
+      double* g1 = v.cG + (size_t(arg.s1) * sB + b) * N * N;
+      double* l1 = v.cLam + (size_t(arg.s1) * sB + b) * N * N;
+      for (int e0 = 0; e0 < N * N; e0 += kWave) {
+        const int e = e0 + lane < N * N ? e0 + lane : N * N - 1;
+        const double gv = g1[e], lv = l1[e];
+        v.ck_G[ck * N * N + e] = gv;
+        v.ck_Lam[ck * N * N + e] = lv;
+        __builtin_amdgcn_wave_barrier();  // (the duplicate lanes have read the entry before anyone resets it)
+        g1[e] = (e / N == e % N) ? 1.0 : 0.0;
+        l1[e] = 0.0;
+      }
+      double* xi1 = v.cxi + (size_t(arg.s1) * sB + b) * N * d;
+      double* cxi = v.ck_xi + ck * N * d;
+      for (int e0 = 0; e0 < nd; e0 += kWave) {
+        const int e = e0 + lane < nd ? e0 + lane : nd - 1;
+        const double x = xi1[e];
+        cxi[e] = x;
+        __builtin_amdgcn_wave_barrier();
+        xi1[e] = 0.0;
+      }
+    }
+    v.ck_steps[ck] = arg.steps;
+    v.ck_sigma[ck] = load_written(v.sigma + size_t(arg.s1) * sB + b);
+    return;
+  }
+
+  LanePrior<N> P;
+  load_lane_prior<N>(Kc, P, l);
+  const double sigma = load_written(v.sigma + size_t(arg.s1) * sB + b);
+  const double dt0 = arg.t - arg.t0, dt1 = arg.t1 - arg.t;
+  double p[N], pinv[N], pl, pil;
+  preconditioner_lanes<N>(dt0, P.fact, l, p, pinv, pl, pil);
+
+  double R0[N], Rt[N], Gt[N], RLt[N];
+  ln::load_cols<N>(v.fac + (size_t(arg.s0) * sB + b) * N * N, R0, l);
+  ln::time_update<N, FP>(P.arow, P.qcol, R0, pinv, pl, pil, sigma, l, Rt, Gt, RLt);
+
+  if constexpr (!FP) {
+    // filter: the solution at t is the prediction from INTERP_FROM; it becomes the new INTERP_FROM
+    for (int j0 = 0; j0 < d; j0 += kWave) {
+      const int j = j0 + lane;
+      const bool on = j < d;
+      const int jc = on ? j : d - 1;
+      double mp[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) mp[i] = pinv[i] * m0[i * d + jc];
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        double acc = 0.0;
+#pragma unroll
+        for (int kk = i; kk < N; ++kk) acc += K.a[i][kk] * mp[kk];
+        const double e = p[i] * acc;
+        m0[i * d + jc] = e;
+        cm[i * d + jc] = e;
+      }
+    }
+    ln::store_cols<N>(v.fac + (size_t(arg.s0) * sB + b) * N * N, Rt, l);
+    ln::store_cols<N>(v.ck_fac + ck * N * N, Rt, l);
+    v.sigma[size_t(arg.s0) * sB + b] = sigma;
+    v.ck_steps[ck] = arg.steps;
+    v.ck_sigma[ck] = sigma;
+    return;
+  } else {
+    // fixedpoint: (i) t0 -> t with merged backward transition, (ii) t -> t1 from an identity
+    // transition, (iii) marginalise STEP_FROM through the t1 -> t transition.
+    double q[N], qinv[N], ql, qil;
+    preconditioner_lanes<N>(dt1, P.fact, l, q, qinv, ql, qil);
+    double Runused[N], G1[N], RL1[N];
+    ln::time_update<N, true>(P.arow, P.qcol, Rt, qinv, ql, qil, sigma, l, Runused, G1, RL1);
+
+    double G0[N], RL0[N];
+    ln::load_rows<N>(v.cG + (size_t(arg.s0) * sB + b) * N * N, G0, l);
+    ln::load_cols<N>(v.cLam + (size_t(arg.s0) * sB + b) * N * N, RL0, l);
+    double* xi0 = v.cxi + (size_t(arg.s0) * sB + b) * N * d;
+    double* xi1 = v.cxi + (size_t(arg.s1) * sB + b) * N * d;
+    double* cxi = v.ck_xi + ck * N * d;
+    for (int j0 = 0; j0 < d; j0 += kWave) {
+      const int j = j0 + lane;
+      const bool on = j < d;
+      const int jc = on ? j : d - 1;
+      double mo[N], mt[N], mt1[N], tmp[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        mo[i] = m0[i * d + jc];
+        tmp[i] = pinv[i] * mo[i];
+      }
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        double acc = 0.0;
+#pragma unroll
+        for (int kk = i; kk < N; ++kk) acc += K.a[i][kk] * tmp[kk];
+        mt[i] = p[i] * acc;  // filtering mean at t
+      }
+#pragma unroll
+      for (int i = 0; i < N; ++i) tmp[i] = qinv[i] * mt[i];
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        double acc = 0.0;
+#pragma unroll
+        for (int kk = i; kk < N; ++kk) acc += K.a[i][kk] * tmp[kk];
+        mt1[i] = q[i] * acc;  // prediction of t1 from t
+      }
+      // xi of (t0 -> t), merged with the running transition of INTERP_FROM
+      double xit[N], cx[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        xit[i] = mo[i];
+        cx[i] = xi0[i * d + jc];
+      }
+      ln::opaque(Gt);
+      ln::opaque(G0);
+      ln::opaque(G1);
+      ln::matvec_rows<N, -1>(Gt, mt, xit);
+      ln::matvec_rows<N, +1>(G0, xit, cx);
+      // xi of (t -> t1); smoothed mean at t
+      double m1v[N], x1[N], ms[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        m1v[i] = m1[i * d + jc];
+        x1[i] = mt[i];
+        ms[i] = 0.0;
+      }
+      ln::matvec_rows<N, -1>(G1, mt1, x1);
+      ln::matvec_rows<N, +1>(G1, m1v, ms);
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        cxi[i * d + jc] = cx[i];
+        xi1[i * d + jc] = x1[i];        // STEP_FROM now remembers how to get back to t
+        cm[i * d + jc] = ms[i] + x1[i];  // solution at the checkpoint
+        m0[i * d + jc] = mt[i];         // INTERP_FROM <- filtering state at t
+        xi0[i * d + jc] = 0.0;          //   ... with an identity backward transition
+      }
+    }
+    // checkpoint factor: qr_r([R1 G1^T ; RL1])
+    {
+      double R1[N], X[N], Ts[N], PT[N], PB[N];
+      ln::load_cols<N>(v.fac + (size_t(arg.s1) * sB + b) * N * N, R1, l);
+#pragma unroll
+      for (int c = 0; c < N; ++c) {  // row c of R1 G1^T, col-lane
+        double acc = 0.0;
+        ln::sfor<0, N>([&](auto kc) PNODE_LAMBDA_INLINE {
+          constexpr int kk = decltype(kc)::value;
+          acc += ln::bcast<kk>(R1[c]) * G1[kk];
+        });
+        X[c] = acc;
+      }
+#pragma unroll
+      for (int r = 0; r < N; ++r) Ts[r] = (l >= r) ? RL1[r] : 0.0;
+      ln::qr_stack<N, false>(Ts, X, PT, PB, l);
+      ln::store_cols<N>(v.ck_fac + ck * N * N, Ts, l);
+    }
+    // checkpoint backward transition = merged (t0 -> t) transition
+    ln::merge<N>(G0, RL0, Gt, RLt, l);
+    ln::store_rows<N>(v.ck_G + ck * N * N, Gt, l);
+    ln::store_cols<N>(v.ck_Lam + ck * N * N, RLt, l);
+    // STEP_FROM transition <- (t1 -> t); INTERP_FROM <- (filter state at t, identity)
+    ln::store_rows<N>(v.cG + (size_t(arg.s1) * sB + b) * N * N, G1, l);
+    ln::store_cols<N>(v.cLam + (size_t(arg.s1) * sB + b) * N * N, RL1, l);
+    ln::store_cols<N>(v.fac + (size_t(arg.s0) * sB + b) * N * N, Rt, l);
+    {
+      double* g0 = v.cG + (size_t(arg.s0) * sB + b) * N * N;
+      double* l0 = v.cLam + (size_t(arg.s0) * sB + b) * N * N;
+#pragma unroll
+      for (int c = 0; c < N; ++c) {
+        g0[l * N + c] = (l == c) ? 1.0 : 0.0;
+        l0[l * N + c] = 0.0;
+      }
+    }
+    v.sigma[size_t(arg.s0) * sB + b] = sigma;
+    v.ck_steps[ck] = arg.steps;
+    v.ck_sigma[ck] = sigma;
+  }
+}
+
 // Device-resident controller (opt-in): every wavefront runs the accept/reject loop and the PI
 // step-size law for ITS trajectory until the next save_at point is reached (or an iteration budget is spent), so
 // the host synchronises once per checkpoint interval instead of once per attempted step. Same arithmetic as the
@@ -468,9 +680,49 @@ __device__ __forceinline__ bool iso_after_attempt(TrajCtl& c, const ControlParam
   return accept;
 }
 
-template <int N, bool FP, int W, bool REGS>
+// With a CkptPlan the launch also does what the host does between two launches otherwise: every save_at point STEP_FROM has reached
+// or passed is stored (interpolation between INTERP_FROM and STEP_FROM, or the right corner), the next one becomes t_stop.
+// Returns false when the last point is stored (c.status = 1).
+template <int N, bool FP>
+__device__ __forceinline__ bool iso_walk_checkpoints(const IsoView& v, const IwpConst* __restrict__ Kc, const CkptPlan& plan, const ControlParams& cp,
+                                                     int b, int lane, TrajCtl& c, int& cursor, bool& touched) {
+  const double* sa = plan.save_at + (plan.per_traj ? size_t(b) * (plan.K + 1) : 0);
+  while (cursor <= plan.K) {
+    const double nxt = sa[cursor];
+    if (!(c.t_sf + cp.numerical_zero >= nxt)) break;
+    InterpArg a;
+    a.t0 = c.t_if; a.t1 = c.t_sf; a.s0 = c.s_if; a.s1 = c.s_sf; a.ckpt = cursor - 1; a.steps = c.steps;
+    if (c.t_sf > nxt + cp.numerical_zero) {  // passed: interpolate, INTERP_FROM moves to the checkpoint
+      a.t = nxt; a.at_step = 0;
+      iso_interp_body<N, FP>(v, Kc, b, lane, a);
+      c.t_if = nxt;
+    } else {  // reached: STEP_FROM is the checkpoint
+      a.t = c.t_sf; a.at_step = 1;
+      iso_interp_body<N, FP>(v, Kc, b, lane, a);
+      c.s_if = c.s_sf;
+      c.t_if = c.t_sf;
+      int fr = 0;
+      while (fr == c.s_sf) ++fr;
+      c.s_pr = fr;
+    }
+    plan.num_steps[size_t(b) * (plan.K + 1) + cursor] = c.steps;
+    ++cursor;
+    touched = true;
+    __threadfence_block();  // (the slots the checkpoint rewrote are read by the next checkpoint / the next attempt)
+  }
+  if (cursor > plan.K) {
+    c.status = 1;
+    return false;
+  }
+  c.t_stop = sa[cursor];
+  return true;
+}
+
+// WALK: the kernel contains the checkpoint code and honours the CkptPlan (instantiated for nu <= 5: with the smoother's checkpoint
+// inlined, the kernels of higher order would need scratch memory; they end at t_stop and leave the checkpoint to the host).
+template <int N, bool FP, int W, bool REGS, bool WALK>
 __global__ __launch_bounds__(256) void iso_advance_kernel(IsoView v, TrajCtl* __restrict__ ctl, const IwpConst* __restrict__ Kc,
-                                                          ControlParams cp) {
+                                                          ControlParams cp, CkptPlan plan) {
   extern __shared__ double smem[];
   constexpr int TPB = 4 / W;
   const int lane = threadIdx.x % (kWave * W);
@@ -482,75 +734,147 @@ __global__ __launch_bounds__(256) void iso_advance_kernel(IsoView v, TrajCtl* __
   double* ybuf = smem + size_t(team) * ((size_t(v.k) + 1) * v.d + 4);
   double* zbuf = ybuf + size_t(v.k) * v.d;
   double* red = zbuf + v.d;
-  LanePrior<N> P;
-  load_lane_prior<N>(Kc, P, ln::col_index<N>(lane));
   int iters = 0;
   c.status = 0;
-  if constexpr (REGS) {
-    static_assert(W == 1, "register form: one wavefront per trajectory");
-    if constexpr (FP) {
-      // the smoother: the state AND the running backward transition stay in registers
-      const IwpConst& K = *Kc;
-      const double atol = v.atol[b], rtol = v.rtol[b];
-      double cm[N], cR[N], csig, cG[N], cRL[N], cxi[N];
-      iso_load_regs<N>(v, b, lane, c.s_sf, cm, cR, csig);
-      iso_load_cond<N>(v, b, lane, c.s_sf, cG, cRL, cxi);
-      while (c.t_sf + cp.numerical_zero < c.t_stop && iters < cp.max_iters) {
-        double dt = c.dt;
-        if (cp.clip) dt = fmin(dt, c.t_stop - c.t_sf);
-        double nm[N], nR[N], nsig, nG[N], nRL[N], nxi[N];
-        double me[N];
-        const double e = iso_attempt_regs<N, true>(v, K, P, b, lane, dt, c.t_sf, cm, cR, csig, nm, nR, nsig, atol, rtol, ybuf, me, &cG, &cRL,
-                                                   &cxi, &nG, &nRL, &nxi);
-        ++iters;
-        const int dst = c.s_pr;
-        if (iso_after_attempt(c, cp, e, dt)) {
-          iso_store_regs<N>(v, b, lane, dst, nm, nR, nsig);
-          iso_store_cond<N>(v, b, lane, dst, nG, nRL, nxi);
-          iso_copy_regs<N>(cm, cR, csig, nm, nR, nsig);
-          iso_copy_cond<N>(cG, cRL, cxi, nG, nRL, nxi);
+  // (Nothing of the stepping loop is live across a checkpoint: the per-lane constants and the register state are loaded again
+  // after it -- once per checkpoint interval -- so that the register budget is the larger of the two phases, not their sum.)
+  const bool walk = WALK && plan.save_at != nullptr;
+  int cursor = walk ? plan.cursor[b] : 0;
+  // the checkpoints are one wavefront's work (the first of a team); the others wait at the barrier
+  auto checkpoints = [&](bool& touched) {
+    bool more = true;
+    if constexpr (!WALK) {
+      return more;
+    } else if constexpr (W == 1) {
+      more = iso_walk_checkpoints<N, FP>(v, Kc, plan, cp, b, lane, c, cursor, touched);
+    } else {
+      __syncthreads();
+      // (every wavefront of the team walks the same uniform bookkeeping; only the first one touches memory)
+      if ((lane >> 6) == 0) {
+        more = iso_walk_checkpoints<N, FP>(v, Kc, plan, cp, b, lane & 63, c, cursor, touched);
+        __threadfence_block();
+      }
+      __syncthreads();
+      // the other wavefronts repeat the bookkeeping without the memory work
+      if ((lane >> 6) != 0) {
+        const double* sa = plan.save_at + (plan.per_traj ? size_t(b) * (plan.K + 1) : 0);
+        while (cursor <= plan.K) {
+          const double nxt = sa[cursor];
+          if (!(c.t_sf + cp.numerical_zero >= nxt)) break;
+          if (c.t_sf > nxt + cp.numerical_zero) {
+            c.t_if = nxt;
+          } else {
+            c.s_if = c.s_sf;
+            c.t_if = c.t_sf;
+            int fr = 0;
+            while (fr == c.s_sf) ++fr;
+            c.s_pr = fr;
+          }
+          ++cursor;
+          touched = true;
         }
-        if (c.status == 2) break;
+        if (cursor > plan.K) {
+          c.status = 1;
+          more = false;
+        } else {
+          c.t_stop = sa[cursor];
+        }
       }
     }
-    if constexpr (!FP) {
-      // the last accepted state stays in registers; a state goes to its slot when it is accepted (the slots STEP_FROM and
-      // INTERP_FROM are what the host reads after the launch), a rejected attempt leaves no trace
-      const IwpConst& K = *Kc;
-      const double atol = v.atol[b], rtol = v.rtol[b];
-      double cm[N], cR[N], csig;
-      iso_load_regs<N>(v, b, lane, c.s_sf, cm, cR, csig);
-      while (c.t_sf + cp.numerical_zero < c.t_stop && iters < cp.max_iters) {
-        double dt = c.dt;
-        if (cp.clip) dt = fmin(dt, c.t_stop - c.t_sf);
-        double nm[N], nR[N], nsig;
-        double me[N];
-        const double e = iso_attempt_regs<N>(v, K, P, b, lane, dt, c.t_sf, cm, cR, csig, nm, nR, nsig, atol, rtol, ybuf, me);
-        ++iters;
-        const int dst = c.s_pr;
-        if (iso_after_attempt(c, cp, e, dt)) {
-          iso_store_regs<N>(v, b, lane, dst, nm, nR, nsig);
-          iso_copy_regs<N>(cm, cR, csig, nm, nR, nsig);
+    return more;
+  };
+  if constexpr (REGS) {
+    static_assert(W == 1, "register form: one wavefront per trajectory");
+    const IwpConst& K = *Kc;
+    const double atol = v.atol[b], rtol = v.rtol[b];
+    if constexpr (FP) {
+      // the smoother: the state AND the running backward transition stay in registers
+      for (;;) {
+        if (walk) {
+          bool touched = false;
+          if (!checkpoints(touched)) break;
         }
-        if (c.status == 2) break;
+        LanePrior<N> P;
+        load_lane_prior<N>(Kc, P, ln::col_index<N>(lane));
+        double cm[N], cR[N], csig, cG[N], cRL[N], cxi[N];
+        iso_load_regs<N>(v, b, lane, c.s_sf, cm, cR, csig);
+        iso_load_cond<N>(v, b, lane, c.s_sf, cG, cRL, cxi);
+        while (c.t_sf + cp.numerical_zero < c.t_stop && iters < cp.max_iters) {
+          double dt = c.dt;
+          if (cp.clip) dt = fmin(dt, c.t_stop - c.t_sf);
+          double nm[N], nR[N], nsig, nG[N], nRL[N], nxi[N];
+          double me[N];
+          const double e = iso_attempt_regs<N, true>(v, K, P, b, lane, dt, c.t_sf, cm, cR, csig, nm, nR, nsig, atol, rtol, ybuf, me, &cG, &cRL,
+                                                     &cxi, &nG, &nRL, &nxi);
+          ++iters;
+          const int dst = c.s_pr;
+          if (iso_after_attempt(c, cp, e, dt)) {
+            iso_store_regs<N>(v, b, lane, dst, nm, nR, nsig);
+            iso_store_cond<N>(v, b, lane, dst, nG, nRL, nxi);
+            iso_copy_regs<N>(cm, cR, csig, nm, nR, nsig);
+            iso_copy_cond<N>(cG, cRL, cxi, nG, nRL, nxi);
+          }
+          if (c.status == 2) break;
+        }
+        if (!walk || c.status == 2 || !(c.t_sf + cp.numerical_zero >= c.t_stop)) break;
+        __threadfence_block();  // (the accepted states are in their slots before the checkpoint reads them)
+      }
+    } else {
+      // the last accepted state stays in registers; a state goes to its slot when it is accepted (the slots STEP_FROM and
+      // INTERP_FROM are what the host -- or the checkpoint -- reads), a rejected attempt leaves no trace.
+      for (;;) {
+        if (walk) {
+          bool touched = false;
+          if (!checkpoints(touched)) break;
+        }
+        LanePrior<N> P;
+        load_lane_prior<N>(Kc, P, ln::col_index<N>(lane));
+        double cm[N], cR[N], csig;
+        iso_load_regs<N>(v, b, lane, c.s_sf, cm, cR, csig);
+        while (c.t_sf + cp.numerical_zero < c.t_stop && iters < cp.max_iters) {
+          double dt = c.dt;
+          if (cp.clip) dt = fmin(dt, c.t_stop - c.t_sf);
+          double nm[N], nR[N], nsig;
+          double me[N];
+          const double e = iso_attempt_regs<N>(v, K, P, b, lane, dt, c.t_sf, cm, cR, csig, nm, nR, nsig, atol, rtol, ybuf, me);
+          ++iters;
+          const int dst = c.s_pr;
+          if (iso_after_attempt(c, cp, e, dt)) {
+            iso_store_regs<N>(v, b, lane, dst, nm, nR, nsig);
+            iso_copy_regs<N>(cm, cR, csig, nm, nR, nsig);
+          }
+          if (c.status == 2) break;
+        }
+        if (!walk || c.status == 2 || !(c.t_sf + cp.numerical_zero >= c.t_stop)) break;
+        __threadfence_block();
       }
     }
   } else {
-    while (c.t_sf + cp.numerical_zero < c.t_stop && iters < cp.max_iters) {
-      double dt = c.dt;
-      if (cp.clip) dt = fmin(dt, c.t_stop - c.t_sf);
-      StepArg arg;
-      arg.dt = dt; arg.t = c.t_sf; arg.src = c.s_sf; arg.dst = c.s_pr; arg.active = 1; arg.pad = 0;
-      const double e = iso_attempt<N, FP, W, false>(v, *Kc, P, b, lane, arg, ybuf, zbuf, red);
-      if constexpr (W > 1) __syncthreads();
-      __threadfence_block();  // the slot written by this attempt is read by the next one (other lanes of the team)
-      ++iters;
-      iso_after_attempt(c, cp, e, dt);
-      if (c.status == 2) break;
+    for (;;) {
+      if (walk) {
+        bool touched = false;
+        if (!checkpoints(touched)) break;
+      }
+      LanePrior<N> P;
+      load_lane_prior<N>(Kc, P, ln::col_index<N>(lane));
+      while (c.t_sf + cp.numerical_zero < c.t_stop && iters < cp.max_iters) {
+        double dt = c.dt;
+        if (cp.clip) dt = fmin(dt, c.t_stop - c.t_sf);
+        StepArg arg;
+        arg.dt = dt; arg.t = c.t_sf; arg.src = c.s_sf; arg.dst = c.s_pr; arg.active = 1; arg.pad = 0;
+        const double e = iso_attempt<N, FP, W, false>(v, *Kc, P, b, lane, arg, ybuf, zbuf, red);
+        if constexpr (W > 1) __syncthreads();
+        __threadfence_block();  // the slot written by this attempt is read by the next one (other lanes of the team)
+        ++iters;
+        iso_after_attempt(c, cp, e, dt);
+        if (c.status == 2) break;
+      }
+      if (!walk || c.status == 2 || !(c.t_sf + cp.numerical_zero >= c.t_stop)) break;
     }
   }
   if (c.status == 0) c.status = (c.t_sf + cp.numerical_zero >= c.t_stop) ? 1 : 3;
   ctl[b] = c;
+  if (walk) plan.cursor[b] = cursor;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -763,206 +1087,13 @@ __global__ __launch_bounds__(256) void iso_advance_fp_kernel(IsoView v, TrajCtl*
 template <int N, bool FP>
 __global__ __launch_bounds__(256) void iso_interp_kernel(IsoView v, const InterpArg* __restrict__ args,
                                                          const IwpConst* __restrict__ Kc) {
-  const int lane = threadIdx.x & 63, l = ln::col_index<N>(lane);
+  const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   const int b = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv);
   if (b >= v.B) return;
   const InterpArg arg = args[b];
   if (arg.ckpt < 0) return;
-  const IwpConst& K = *Kc;
-  const int d = v.d;
-  const size_t sB = size_t(v.B);
-  const size_t ck = size_t(b) * v.K + arg.ckpt;
-  double* m0 = v.mean + (size_t(arg.s0) * sB + b) * N * d;
-  double* m1 = v.mean + (size_t(arg.s1) * sB + b) * N * d;
-  double* cm = v.ck_mean + ck * N * d;
-
-  if (arg.at_step) {
-    // checkpoint coincides with STEP_FROM: store it; fixedpoint resets the backward transition
-    // (wave-uniform trip counts, clamped indices, unpredicated stores: the duplicate lanes repeat their neighbour's copy)
-    const int nd = N * d;
-    for (int e0 = 0; e0 < nd; e0 += kWave) {
-      const int e = e0 + lane < nd ? e0 + lane : nd - 1;
-      cm[e] = m1[e];
-    }
-    const double* f1 = v.fac + (size_t(arg.s1) * sB + b) * N * N;
-    for (int e0 = 0; e0 < N * N; e0 += kWave) {
-      const int e = e0 + lane < N * N ? e0 + lane : N * N - 1;
-      v.ck_fac[ck * N * N + e] = f1[e];
-    }
-    if constexpr (FP) {
-      double* g1 = v.cG + (size_t(arg.s1) * sB + b) * N * N;
-      double* l1 = v.cLam + (size_t(arg.s1) * sB + b) * N * N;
-      for (int e0 = 0; e0 < N * N; e0 += kWave) {
-        const int e = e0 + lane < N * N ? e0 + lane : N * N - 1;
-        const double gv = g1[e], lv = l1[e];
-        v.ck_G[ck * N * N + e] = gv;
-        v.ck_Lam[ck * N * N + e] = lv;
-        __builtin_amdgcn_wave_barrier();  // (the duplicate lanes have read the entry before anyone resets it)
-        g1[e] = (e / N == e % N) ? 1.0 : 0.0;
-        l1[e] = 0.0;
-      }
-      double* xi1 = v.cxi + (size_t(arg.s1) * sB + b) * N * d;
-      double* cxi = v.ck_xi + ck * N * d;
-      for (int e0 = 0; e0 < nd; e0 += kWave) {
-        const int e = e0 + lane < nd ? e0 + lane : nd - 1;
-        const double x = xi1[e];
-        cxi[e] = x;
-        __builtin_amdgcn_wave_barrier();
-        xi1[e] = 0.0;
-      }
-    }
-    v.ck_steps[ck] = arg.steps;
-    v.ck_sigma[ck] = v.sigma[size_t(arg.s1) * sB + b];
-    return;
-  }
-
-  LanePrior<N> P;
-  load_lane_prior<N>(Kc, P, l);
-  const double sigma = v.sigma[size_t(arg.s1) * sB + b];
-  const double dt0 = arg.t - arg.t0, dt1 = arg.t1 - arg.t;
-  double p[N], pinv[N], pl, pil;
-  preconditioner_lanes<N>(dt0, P.fact, l, p, pinv, pl, pil);
-
-  double R0[N], Rt[N], Gt[N], RLt[N];
-  ln::load_cols<N>(v.fac + (size_t(arg.s0) * sB + b) * N * N, R0, l);
-  ln::time_update<N, FP>(P.arow, P.qcol, R0, pinv, pl, pil, sigma, l, Rt, Gt, RLt);
-
-  if constexpr (!FP) {
-    // filter: the solution at t is the prediction from INTERP_FROM; it becomes the new INTERP_FROM
-    for (int j0 = 0; j0 < d; j0 += kWave) {
-      const int j = j0 + lane;
-      const bool on = j < d;
-      const int jc = on ? j : d - 1;
-      double mp[N];
-#pragma unroll
-      for (int i = 0; i < N; ++i) mp[i] = pinv[i] * m0[i * d + jc];
-#pragma unroll
-      for (int i = 0; i < N; ++i) {
-        double acc = 0.0;
-#pragma unroll
-        for (int kk = i; kk < N; ++kk) acc += K.a[i][kk] * mp[kk];
-        const double e = p[i] * acc;
-        m0[i * d + jc] = e;
-        cm[i * d + jc] = e;
-      }
-    }
-    ln::store_cols<N>(v.fac + (size_t(arg.s0) * sB + b) * N * N, Rt, l);
-    ln::store_cols<N>(v.ck_fac + ck * N * N, Rt, l);
-    v.sigma[size_t(arg.s0) * sB + b] = sigma;
-    v.ck_steps[ck] = arg.steps;
-    v.ck_sigma[ck] = sigma;
-    return;
-  } else {
-    // fixedpoint: (i) t0 -> t with merged backward transition, (ii) t -> t1 from an identity
-    // transition, (iii) marginalise STEP_FROM through the t1 -> t transition.
-    double q[N], qinv[N], ql, qil;
-    preconditioner_lanes<N>(dt1, P.fact, l, q, qinv, ql, qil);
-    double Runused[N], G1[N], RL1[N];
-    ln::time_update<N, true>(P.arow, P.qcol, Rt, qinv, ql, qil, sigma, l, Runused, G1, RL1);
-
-    double G0[N], RL0[N];
-    ln::load_rows<N>(v.cG + (size_t(arg.s0) * sB + b) * N * N, G0, l);
-    ln::load_cols<N>(v.cLam + (size_t(arg.s0) * sB + b) * N * N, RL0, l);
-    double* xi0 = v.cxi + (size_t(arg.s0) * sB + b) * N * d;
-    double* xi1 = v.cxi + (size_t(arg.s1) * sB + b) * N * d;
-    double* cxi = v.ck_xi + ck * N * d;
-    for (int j0 = 0; j0 < d; j0 += kWave) {
-      const int j = j0 + lane;
-      const bool on = j < d;
-      const int jc = on ? j : d - 1;
-      double mo[N], mt[N], mt1[N], tmp[N];
-#pragma unroll
-      for (int i = 0; i < N; ++i) {
-        mo[i] = m0[i * d + jc];
-        tmp[i] = pinv[i] * mo[i];
-      }
-#pragma unroll
-      for (int i = 0; i < N; ++i) {
-        double acc = 0.0;
-#pragma unroll
-        for (int kk = i; kk < N; ++kk) acc += K.a[i][kk] * tmp[kk];
-        mt[i] = p[i] * acc;  // filtering mean at t
-      }
-#pragma unroll
-      for (int i = 0; i < N; ++i) tmp[i] = qinv[i] * mt[i];
-#pragma unroll
-      for (int i = 0; i < N; ++i) {
-        double acc = 0.0;
-#pragma unroll
-        for (int kk = i; kk < N; ++kk) acc += K.a[i][kk] * tmp[kk];
-        mt1[i] = q[i] * acc;  // prediction of t1 from t
-      }
-      // xi of (t0 -> t), merged with the running transition of INTERP_FROM
-      double xit[N], cx[N];
-#pragma unroll
-      for (int i = 0; i < N; ++i) {
-        xit[i] = mo[i];
-        cx[i] = xi0[i * d + jc];
-      }
-      ln::opaque(Gt);
-      ln::opaque(G0);
-      ln::opaque(G1);
-      ln::matvec_rows<N, -1>(Gt, mt, xit);
-      ln::matvec_rows<N, +1>(G0, xit, cx);
-      // xi of (t -> t1); smoothed mean at t
-      double m1v[N], x1[N], ms[N];
-#pragma unroll
-      for (int i = 0; i < N; ++i) {
-        m1v[i] = m1[i * d + jc];
-        x1[i] = mt[i];
-        ms[i] = 0.0;
-      }
-      ln::matvec_rows<N, -1>(G1, mt1, x1);
-      ln::matvec_rows<N, +1>(G1, m1v, ms);
-#pragma unroll
-      for (int i = 0; i < N; ++i) {
-        cxi[i * d + jc] = cx[i];
-        xi1[i * d + jc] = x1[i];        // STEP_FROM now remembers how to get back to t
-        cm[i * d + jc] = ms[i] + x1[i];  // solution at the checkpoint
-        m0[i * d + jc] = mt[i];         // INTERP_FROM <- filtering state at t
-        xi0[i * d + jc] = 0.0;          //   ... with an identity backward transition
-      }
-    }
-    // checkpoint factor: qr_r([R1 G1^T ; RL1])
-    {
-      double R1[N], X[N], Ts[N], PT[N], PB[N];
-      ln::load_cols<N>(v.fac + (size_t(arg.s1) * sB + b) * N * N, R1, l);
-#pragma unroll
-      for (int c = 0; c < N; ++c) {  // row c of R1 G1^T, col-lane
-        double acc = 0.0;
-        ln::sfor<0, N>([&](auto kc) PNODE_LAMBDA_INLINE {
-          constexpr int kk = decltype(kc)::value;
-          acc += ln::bcast<kk>(R1[c]) * G1[kk];
-        });
-        X[c] = acc;
-      }
-#pragma unroll
-      for (int r = 0; r < N; ++r) Ts[r] = (l >= r) ? RL1[r] : 0.0;
-      ln::qr_stack<N, false>(Ts, X, PT, PB, l);
-      ln::store_cols<N>(v.ck_fac + ck * N * N, Ts, l);
-    }
-    // checkpoint backward transition = merged (t0 -> t) transition
-    ln::merge<N>(G0, RL0, Gt, RLt, l);
-    ln::store_rows<N>(v.ck_G + ck * N * N, Gt, l);
-    ln::store_cols<N>(v.ck_Lam + ck * N * N, RLt, l);
-    // STEP_FROM transition <- (t1 -> t); INTERP_FROM <- (filter state at t, identity)
-    ln::store_rows<N>(v.cG + (size_t(arg.s1) * sB + b) * N * N, G1, l);
-    ln::store_cols<N>(v.cLam + (size_t(arg.s1) * sB + b) * N * N, RL1, l);
-    ln::store_cols<N>(v.fac + (size_t(arg.s0) * sB + b) * N * N, Rt, l);
-    {
-      double* g0 = v.cG + (size_t(arg.s0) * sB + b) * N * N;
-      double* l0 = v.cLam + (size_t(arg.s0) * sB + b) * N * N;
-#pragma unroll
-      for (int c = 0; c < N; ++c) {
-        g0[l * N + c] = (l == c) ? 1.0 : 0.0;
-        l0[l * N + c] = 0.0;
-      }
-    }
-    v.sigma[size_t(arg.s0) * sB + b] = sigma;
-    v.ck_steps[ck] = arg.steps;
-    v.ck_sigma[ck] = sigma;
-  }
+  iso_interp_body<N, FP>(v, Kc, b, lane, arg);
 }
 
 // Backward pass over the stored checkpoint transitions (stats.markov_marginals(reverse=True),
@@ -1203,13 +1334,25 @@ void iso_launch_interp(const IsoView& v, const InterpArg* args, const IwpConst* 
   PNODE_DISPATCH_N(v.n, CALL)
 #undef CALL
 }
+constexpr int kWalkMaxN = 6;  // checkpoints inside the controller kernel up to nu = 5 (beyond: scratch memory, see iso_advance_kernel)
+template <int N, bool FP, int W, bool REGS>
+static void launch_advance_one(const IsoView& v, TrajCtl* ctl, const IwpConst* K, const ControlParams& cp, hipStream_t s, const CkptPlan& plan,
+                               dim3 grid, size_t shm) {
+  if constexpr (N <= kWalkMaxN) {
+    if (plan.save_at) {
+      hipLaunchKernelGGL((iso_advance_kernel<N, FP, W, REGS, true>), grid, dim3(256), shm, s, v, ctl, K, cp, plan);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((iso_advance_kernel<N, FP, W, REGS, false>), grid, dim3(256), shm, s, v, ctl, K, cp, plan);
+}
 template <int N>
-static void launch_advance_n(const IsoView& v, TrajCtl* ctl, const IwpConst* K, const ControlParams& cp, hipStream_t s) {
+static void launch_advance_n(const IsoView& v, TrajCtl* ctl, const IwpConst* K, const ControlParams& cp, hipStream_t s, const CkptPlan& plan) {
   if (iso_wide(v)) {
     if (v.fixedpoint)
-      hipLaunchKernelGGL((iso_advance_kernel<N, true, 4, false>), dim3(v.B), dim3(256), iso_shm(v, 1), s, v, ctl, K, cp);
+      launch_advance_one<N, true, 4, false>(v, ctl, K, cp, s, plan, dim3(v.B), iso_shm(v, 1));
     else
-      hipLaunchKernelGGL((iso_advance_kernel<N, false, 4, false>), dim3(v.B), dim3(256), iso_shm(v, 1), s, v, ctl, K, cp);
+      launch_advance_one<N, false, 4, false>(v, ctl, K, cp, s, plan, dim3(v.B), iso_shm(v, 1));
     return;
   }
   const int blocks = (v.B + 3) / 4;
@@ -1223,21 +1366,24 @@ static void launch_advance_n(const IsoView& v, TrajCtl* ctl, const IwpConst* K, 
     hipLaunchKernelGGL((iso_advance_fp_kernel<N>), dim3(v.B), dim3(256), iso_fp_shm_doubles(N, v.k, v.d) * sizeof(double), s, v, ctl, K, cp);
     return;
   }
-  const bool regs = v.d <= kWave;
+  const bool regs = v.d <= kWave;  // one ODE dimension per lane: the state of a trajectory in the registers of its wavefront
+  const size_t shm = iso_shm(v, 4);
   if (v.fixedpoint) {
     if (regs)
-      hipLaunchKernelGGL((iso_advance_kernel<N, true, 1, true>), dim3(blocks), dim3(256), iso_shm(v, 4), s, v, ctl, K, cp);
+      launch_advance_one<N, true, 1, true>(v, ctl, K, cp, s, plan, dim3(blocks), shm);
     else
-      hipLaunchKernelGGL((iso_advance_kernel<N, true, 1, false>), dim3(blocks), dim3(256), iso_shm(v, 4), s, v, ctl, K, cp);
+      launch_advance_one<N, true, 1, false>(v, ctl, K, cp, s, plan, dim3(blocks), shm);
   } else {
     if (regs)
-      hipLaunchKernelGGL((iso_advance_kernel<N, false, 1, true>), dim3(blocks), dim3(256), iso_shm(v, 4), s, v, ctl, K, cp);
+      launch_advance_one<N, false, 1, true>(v, ctl, K, cp, s, plan, dim3(blocks), shm);
     else
-      hipLaunchKernelGGL((iso_advance_kernel<N, false, 1, false>), dim3(blocks), dim3(256), iso_shm(v, 4), s, v, ctl, K, cp);
+      launch_advance_one<N, false, 1, false>(v, ctl, K, cp, s, plan, dim3(blocks), shm);
   }
 }
-void iso_launch_advance(const IsoView& v, TrajCtl* ctl, const IwpConst* K, const ControlParams& cp, hipStream_t s) {
-#define CALL(NN) launch_advance_n<NN>(v, ctl, K, cp, s)
+bool iso_advance_walks_checkpoints(const IsoView& v) { return v.n <= kWalkMaxN && !(v.fixedpoint && v.d <= kWave && v.fp_pipeline == 1 && !iso_wide(v)); }
+
+void iso_launch_advance(const IsoView& v, TrajCtl* ctl, const IwpConst* K, const ControlParams& cp, hipStream_t s, const CkptPlan& plan) {
+#define CALL(NN) launch_advance_n<NN>(v, ctl, K, cp, s, plan)
   PNODE_DISPATCH_N(v.n, CALL)
 #undef CALL
 }

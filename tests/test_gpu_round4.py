@@ -151,3 +151,41 @@ def test_experiment_3_result_files_have_the_reference_schema(hip_lib, golden, tm
     assert np.allclose(np.load(tmp_path / "data_checkpoints.npy"), g["checkpoints"])
     ts, ys = np.load(tmp_path / "data_ts.npy"), np.load(tmp_path / "data_ys.npy")
     assert ys.shape == (len(ts), 28) and ts[0] == 0.0 and ts[-1] == 3.0
+
+
+@pytest.mark.parametrize("strategy", ["filter", "fixedpoint"])
+@pytest.mark.parametrize("N", [8, 40])
+def test_checkpoints_inside_the_controller_kernel(hip_lib, N, strategy):
+    """Isotropic model, device-resident controller, nu <= 5: the launch walks over the save_at points itself (interpolation and right
+    corner inside the controller kernel, csrc/pnode_iso.hip: iso_walk_checkpoints) -- the host's loop of
+    /root/reference/src/odecheckpts/ivpsolvers.py:71-77 moved onto the device. 60 save_at points at loose tolerances, so that one
+    accepted step passes several of them; trajectories of different speed in one batch; an iteration budget of 7 attempts per launch,
+    so that the solve is spread over many launches that resume mid-interval: accepted-step counts AT EVERY CHECKPOINT, attempts and
+    (smoothed) means as with the host controller. d = 16 runs the register form, d = 80 the loops over the ODE dimensions."""
+    from probdiffeq_hip import _backend
+
+    vf = V.brusselator(N)
+    impl.select("isotropic", ode_shape=(vf.d,))
+    solver = _solver(3, strategy)
+    tol = np.array([1e-2, 1e-4, 1e-6])
+    y0 = np.stack([brusselator_y0(N, 0.3 * b) for b in range(3)])
+    init = solver.initial_condition(taylor.odejet_padded_scan(vf, [y0], num=3), 1.0)
+    asolver = ivpsolve.adaptive(solver, atol=1e-3 * tol, rtol=tol)
+    save_at = np.linspace(0.0, 1.5, 60)
+    run = lambda dc: ivpsolve.solve_adaptive_save_at(vf, init, save_at=save_at, dt0=0.01, adaptive_solver=asolver, device_controller=dc)
+    host, dev = run(False), run(True)
+    if N == 8:
+        assert np.any(np.diff(host.num_steps[0]) == 0)  # several checkpoints of the loosest member fall into one step (N = 40: stiffer, 20 steps each)
+    assert np.array_equal(dev.num_steps, host.num_steps) and np.array_equal(dev.num_attempts, host.num_attempts)
+    assert relmax(dev.u, host.u) < 1e-10
+    # the same through the C-ABI with a budget of 7 attempts per launch
+    batch = ivpsolve._make_batch(vf, init, solver, len(save_at) - 1)
+    try:
+        batch.set_initial(init.tcoeffs, np.zeros(3), init.output_scale)
+        batch.set_tolerances(1e-3 * tol, tol)
+        steps, attempts, failed = batch.solve_adaptive_save_at(save_at, np.full(3, 0.01), asolver.control, asolver.numerical_zero,
+                                                               max_attempts=7, device_controller=True)
+        assert not failed.any()
+        assert np.array_equal(steps, host.num_steps) and np.array_equal(attempts, host.num_attempts)
+    finally:
+        batch.close()
