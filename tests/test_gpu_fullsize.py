@@ -234,3 +234,40 @@ def test_config2_stiff_tolerance_sweep_full_batch(hip_lib):
     sub = ivpsolve.solve_adaptive_save_at(vf, solver.initial_condition([c[idx] for c in tcs], 1.0), save_at=save_at, dt0=0.01,
                                           adaptive_solver=ivpsolve.adaptive(solver, atol=tols[idx], rtol=tols[idx]))
     assert np.array_equal(sub.num_steps, sol.num_steps[idx]) and np.array_equal(sub.u, sol.u[idx])
+
+
+def test_config5_as_specified_batch_64_with_200_save_at_points(hip_lib):
+    """BASELINE config 5 as specified for one GPU: Brusselator N = 128 (d = 256), nu = 3, dense EKF1 (D = 1024), fixed-memory
+    checkpoint smoothing, 64 trajectories, save_at = 200 points (/root/reference/experiments/4_brusselator/run.py:119) -- the 199
+    stored backward transitions are what makes the run 208 GB of device memory -- over a SHORT time span (the full span is
+    scripts/bench_configs.py c5full, 35 s). The oracle cannot follow at this size in test time (its checks at D = 1024 are
+    test_config5_size_dense_smoother_on_the_large_path); here: finite, every checkpoint stored, the smoothed means against the
+    filter's at the same points and against scipy, and composition invariance -- two members solved alone give the bits of the batch."""
+    from scipy.integrate import solve_ivp
+
+    Nl, nu, tol, B, K = 128, 3, 1e-3, 64, 200
+    vf = V.brusselator(Nl)
+    impl.select("dense", ode_shape=(2 * Nl,))
+    x = np.linspace(0.0, 1.0, Nl)
+    ph = 2.0 * np.pi * np.arange(B) / B
+    y0 = np.concatenate([1.0 + np.sin(2 * np.pi * x[None, :] + ph[:, None]), 3.0 * np.ones((B, Nl))], axis=1)
+    save_at = np.linspace(0.0, 0.02, K)
+    sols = {}
+    for strategy in ("fixedpoint", "filter"):
+        strat = ivpsolvers.strategy_fixedpoint if strategy == "fixedpoint" else ivpsolvers.strategy_filter
+        solver = ivpsolvers.solver_dynamic(strat(ivpsolvers.prior_ibm(nu), ivpsolvers.correction_ts1()))
+        run = lambda idx, sv=solver: ivpsolve.solve_adaptive_save_at(  # noqa: E731
+            vf, sv.initial_condition(tcoeffs(vf, [y0[idx]], nu), 1.0), save_at=save_at, dt0=0.001,
+            adaptive_solver=ivpsolve.adaptive(sv, atol=tol, rtol=tol))
+        sols[strategy] = run(np.arange(B)) if strategy == "fixedpoint" else run(np.array([0, 63]))
+        if strategy == "fixedpoint":
+            sub = run(np.array([0, 63]))
+    fp = sols["fixedpoint"]
+    assert fp.u.shape == (B, K, 2 * Nl) and np.all(np.isfinite(fp.u))
+    assert np.all(np.diff(fp.num_steps, axis=1) >= 0) and fp.num_steps[:, -1].min() >= 3
+    assert np.array_equal(sub.num_steps, fp.num_steps[[0, 63]]) and np.array_equal(sub.u, fp.u[[0, 63]])
+    fl = sols["filter"]
+    assert np.array_equal(fl.num_steps, fp.num_steps[[0, 63]])  # the smoother takes the filter's steps
+    assert np.max(np.abs(fl.u - fp.u[[0, 63]])) < 50 * tol  # smoothed against filtered means: both inside the tolerance band
+    truth = solve_ivp(lambda t, y: np.asarray(vf(y)), (0.0, save_at[-1]), y0[0], rtol=1e-10, atol=1e-10, method="LSODA").y[:, -1]
+    assert np.max(np.abs(fp.u[0, -1] - truth)) < 50 * tol
