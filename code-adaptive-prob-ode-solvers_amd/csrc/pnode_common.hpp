@@ -194,27 +194,4 @@ __host__ __device__ inline double tiled_factor_entry(const double* L, int row, i
   return col < D - d ? L[tiled_index_rt(row, col, tiled_col_tiles(D, d))] : 0.0;
 }
 
-// Rotate the row x (length N) into the upper-triangular R (N x N) with Givens rotations:
-// afterwards R^T R (new) = R^T R (old) + x^T x. Orthogonal transformations only.
-template <int N>
-__device__ __forceinline__ void givens_rotate_in(double (&R)[N][N], double (&x)[N]) {
-#pragma unroll
-  for (int j = 0; j < N; ++j) {
-    const double xj = x[j];
-    if (xj != 0.0) {
-      const double rjj = R[j][j];
-      const double h2 = fma(rjj, rjj, xj * xj);
-      const double inv = fast_rsqrt(h2);
-      const double c = rjj * inv, s = xj * inv;
-      R[j][j] = h2 * inv;
-#pragma unroll
-      for (int l = j + 1; l < N; ++l) {
-        const double rl = R[j][l], xl = x[l];
-        R[j][l] = c * rl + s * xl;
-        x[l] = c * xl - s * rl;
-      }
-    }
-  }
-}
-
 }  // namespace pnode

@@ -5,7 +5,7 @@
 // Same algorithm as pnode_dense.hip (generic path): row-Householder LQ time update, Gram-of-factor innovation,
 // projector-form measurement update. Lane j owns row j in the O(D^3) loops, so there are no cross-lane reductions
 // except the pivot-row norm. Also provides the device-resident controller loop (dense_small_advance_kernel).
-#include "pnode_nxn.hpp"
+#include "pnode_lanes.hpp"
 #include "pnode_vf.hpp"
 
 namespace pnode {
@@ -49,19 +49,49 @@ __device__ __forceinline__ void wsync() {
 
 // ---------------------------------------------------------------------------------------------
 // d = 1 (a scalar ODE of order k <= 2: the reference's stiff Van der Pol run, vdp.py:61-66, BASELINE config 2): the dense model
-// is the isotropic one with one column, the EKF1 observation row is h = e_k - [J_0 .. J_{k-1}], and everything is n x n,
-// wave-uniform, in registers -- no LDS, no wavefront barrier (the general path below: about 40 barriers and 16 k cycles per
-// attempt at D = 5). Time update by Givens rotations (iso_time_update, pnode_nxn.hpp) on R = L^T; measurement update in projector
-// form; calibration from s1^2 = h (P Qbar P) h^T. The state factor is stored as L = R^T (lower triangular, positive diagonal).
+// is the isotropic one with one column, the EKF1 observation row is h = e_k - [J_0 .. J_{k-1}], and everything is n x n --
+// no LDS, no wavefront barrier (the general path below: about 40 barriers and 16 k cycles per attempt at D = 5).
+// r04: the n x n algebra in the lane layout of pnode_lanes.hpp (one column of R = L^T per lane, Householder time update: n
+// reciprocal square roots per attempt where the Givens form of r03 took n^2); the mean, the observation row and every scalar
+// are wave-uniform. Measurement update in projector form; calibration from s1^2 = h (P Qbar P) h^T. The state factor is
+// stored as L = R^T (lower triangular, non-negative diagonal), row-major.
 // ---------------------------------------------------------------------------------------------
-// state in: m, Rprev (= L^T), sigma_prev; out: mnew, Rnew, sigma_out; returns the normalised error norm
 template <int N>
-__device__ __forceinline__ double dense_d1_core(const DenseView& v, const IwpConst& K, int b, double dt, double t, const double (&m)[N],
-                                                const double (&Rprev)[N][N], double sigma_prev, double (&mnew)[N], double (&Rnew)[N][N],
-                                                double& sigma_out, double atol, double rtol) {
+struct D1Prior {
+  double arow[N], qcol[N], qrow[N], fact;  // per lane l: row l of Abar, column l and row l of chol(Qbar)^T, (nu - l)!
+};
+template <int N>
+__device__ __forceinline__ void d1_load_prior(const IwpConst* __restrict__ Kc, D1Prior<N>& P, int l) {
+  ln::load_prior<N>(Kc, P.arow, P.qcol, l);
+  ln::load_rows<N, kMaxN>(&Kc->qsT[0][0], P.qrow, l);
+  P.fact = Kc->fact[l];
+}
+
+// p_i = dt^(nu-i+1/2) / (nu-i)!, pinv_i = 1 / p_i: lane i forms its own pair, the uniform arrays come from row broadcasts
+// (the multiplication sequence of preconditioner(), pnode_common.hpp)
+template <int N>
+__device__ __forceinline__ void d1_preconditioner(double dt, double fact, int l, double (&p)[N], double (&pinv)[N], double& pl, double& pil) {
+  const double adt = fabs(dt);
+  double pw = sqrt(adt);
+#pragma unroll
+  for (int s = 0; s < N - 1; ++s) pw = (N - 1 - l > s) ? pw * adt : pw;
+  pl = pw / fact;
+  pil = fact / pw;
+  ln::sfor<0, N>([&](auto ic) PNODE_LAMBDA_INLINE {
+    constexpr int i = decltype(ic)::value;
+    p[i] = ln::bcast<i>(pl);
+    pinv[i] = ln::bcast<i>(pil);
+  });
+}
+
+// state in: m (uniform), R (= L^T, col-lane), sigma_prev; out: mnew, Rnew, sigma_out; returns the normalised error norm (uniform)
+template <int N>
+__device__ __forceinline__ double dense_d1_core(const DenseView& v, const IwpConst& K, const D1Prior<N>& P, int b, int l, double dt, double t,
+                                                const double (&m)[N], const double (&Rprev)[N], double sigma_prev, double (&mnew)[N],
+                                                double (&Rnew)[N], double& sigma_out, double atol, double rtol) {
   const int k = v.k;
-  double p[N], pinv[N];
-  preconditioner<N>(dt, K, p, pinv);
+  double p[N], pinv[N], pl, pil;
+  d1_preconditioner<N>(dt, P.fact, l, p, pinv, pl, pil);
   // m^- = P Abar P^-1 m
   double me[N];
   {
@@ -92,99 +122,101 @@ __device__ __forceinline__ double dense_d1_core(const DenseView& v, const IwpCon
     h[0] = -vf_jac(ctx, y, 0, 0, 0, tnew);
     if (k > 1) h[1] = -vf_jac(ctx, y, 0, 1, 0, tnew);
   }
-  // calibration + error estimate: s1^2 = h (P Qbar P) h^T = sum_c (sum_i chol(Qbar)^T[c][i] p_i h_i)^2
+  // calibration + error estimate: s1^2 = h (P Qbar P) h^T = sum_c (sum_i chol(Qbar)^T[c][i] p_i h_i)^2, lane c forms term c
   double s1sq = 0.0;
-#pragma unroll
-  for (int c = 0; c < N; ++c) {
+  {
     double b0 = 0.0;
 #pragma unroll
-    for (int i = c; i < N; ++i) b0 += K.qsT[c][i] * (p[i] * h[i]);
-    s1sq += b0 * b0;
+    for (int i = 0; i < N; ++i) b0 += P.qrow[i] * (p[i] * h[i]);
+    ln::sfor<0, N>([&](auto cc) PNODE_LAMBDA_INLINE {
+      constexpr int c = decltype(cc)::value;
+      const double bc = ln::bcast<c>(b0);
+      s1sq += bc * bc;
+    });
   }
   const double s1 = sqrt(overflow_to_nan(s1sq));
   const double sigma_hat = fabs(z) / s1;
   const double err = dt * sigma_hat * s1;
   const double sigma = v.dynamic ? sigma_hat : sigma_prev;
-  double Rm[N][N], Gu[N][N], RLu[N][N];
-  iso_time_update<N, false>(K, Rprev, p, pinv, sigma, Rm, Gu, RLu);
+  double Gu[N], RLu[N];
+  ln::time_update<N, false>(P.arow, P.qcol, Rprev, pinv, pl, pil, sigma, l, Rnew, Gu, RLu);
   // measurement update on z = 0: F = h L^- = (Rm h)^T, gain = Sigma^- h^T / (F F^T), projector form
-  double F[N], gain[N];
+  double hl = h[0];  // my lane's entry of h
+#pragma unroll
+  for (int i = 1; i < N; ++i) hl = (l == i) ? h[i] : hl;
+  double F[N];
   double s2 = 0.0;
 #pragma unroll
   for (int c = 0; c < N; ++c) {
+    const double tc = Rnew[c] * hl;
     double f = 0.0;
-#pragma unroll
-    for (int i = 0; i < N; ++i) f += Rm[c][i] * h[i];
+    ln::sfor<0, N>([&](auto ic) PNODE_LAMBDA_INLINE {
+      constexpr int i = decltype(ic)::value;
+      f += ln::bcast<i>(tc);
+    });
     F[c] = f;
     s2 += f * f;
   }
+  double acc = 0.0;
 #pragma unroll
-  for (int i = 0; i < N; ++i) {
-    double acc = 0.0;
+  for (int c = 0; c < N; ++c) acc += Rnew[c] * F[c];
+  const double gain = acc / overflow_to_nan(s2);  // lane i: gain_i
+  ln::sfor<0, N>([&](auto ic) PNODE_LAMBDA_INLINE {
+    constexpr int i = decltype(ic)::value;
+    mnew[i] = me[i] - ln::bcast<i>(gain) * z;
+  });
 #pragma unroll
-    for (int c = 0; c < N; ++c) acc += Rm[c][i] * F[c];
-    gain[i] = acc / overflow_to_nan(s2);
-  }
-#pragma unroll
-  for (int i = 0; i < N; ++i) mnew[i] = me[i] - gain[i] * z;
-#pragma unroll
-  for (int c = 0; c < N; ++c)
-#pragma unroll
-    for (int i = 0; i < N; ++i) Rnew[c][i] = Rm[c][i] - F[c] * gain[i];
+  for (int c = 0; c < N; ++c) Rnew[c] -= F[c] * gain;
   sigma_out = sigma;
   const double rel = err / (atol + rtol * fabs(mnew[0]));
-  return fabs(rel);
+  return ln::uniform(fabs(rel));
 }
 
 template <int N>
-__device__ __forceinline__ void dense_d1_load(const DenseView& v, int b, int slot, double (&m)[N], double (&R)[N][N], double& sigma) {
+__device__ __forceinline__ void dense_d1_load(const DenseView& v, int b, int l, int slot, double (&m)[N], double (&R)[N], double& sigma) {
   const size_t sB = size_t(v.B);
   const double* msrc = v.mean + (size_t(slot) * sB + b) * N;
-  const double* Lsrc = v.U + (size_t(slot) * sB + b) * N * N;
 #pragma unroll
-  for (int i = 0; i < N; ++i) {
-    m[i] = msrc[i];
-#pragma unroll
-    for (int c = 0; c < N; ++c) R[c][i] = Lsrc[i * N + c];  // R = L^T
-  }
+  for (int i = 0; i < N; ++i) m[i] = msrc[i];
+  ln::load_rows<N>(v.U + (size_t(slot) * sB + b) * N * N, R, l);  // lane l: row l of L = column l of R = L^T
   sigma = v.sigma[size_t(slot) * sB + b];
 }
 
 template <int N>
-__device__ __forceinline__ void dense_d1_store(const DenseView& v, int b, int lane, int slot, const double (&m)[N], const double (&R)[N][N],
-                                               double sigma) {
+__device__ __forceinline__ void dense_d1_store(const DenseView& v, int b, int l, int slot, const double (&m)[N], const double (&R)[N], double sigma) {
   const size_t sB = size_t(v.B);
   double* mdst = v.mean + (size_t(slot) * sB + b) * N;
-  double* Ldst = v.U + (size_t(slot) * sB + b) * N * N;
 #pragma unroll
-  for (int i = 0; i < N; ++i) {
-    if (lane == i) mdst[i] = m[i];
-#pragma unroll
-    for (int c = 0; c < N; ++c)
-      if (lane == ((i * N + c) & 63)) Ldst[i * N + c] = R[c][i];
-  }
-  if (lane == 0) v.sigma[size_t(slot) * sB + b] = sigma;
+  for (int i = 0; i < N; ++i) mdst[i] = m[i];  // (uniform values: every lane writes them)
+  ln::store_rows<N>(v.U + (size_t(slot) * sB + b) * N * N, R, l);
+  v.sigma[size_t(slot) * sB + b] = sigma;
 }
 
 template <int N>
-__device__ __forceinline__ double dense_d1_attempt(const DenseView& v, const IwpConst& K, int b, int lane, const StepArg& arg) {
-  double m[N], R[N][N], sig, mn[N], Rn[N][N], sign;
-  dense_d1_load<N>(v, b, arg.src, m, R, sig);
-  const double e = dense_d1_core<N>(v, K, b, arg.dt, arg.t, m, R, sig, mn, Rn, sign, v.atol[b], v.rtol[b]);
-  dense_d1_store<N>(v, b, lane, arg.dst, mn, Rn, sign);
+__device__ __forceinline__ double dense_d1_attempt(const DenseView& v, const IwpConst* __restrict__ Kc, int b, int lane, const StepArg& arg) {
+  const int l = ln::col_index<N>(lane);
+  D1Prior<N> P;
+  d1_load_prior<N>(Kc, P, l);
+  double m[N], R[N], sig, mn[N], Rn[N], sign;
+  dense_d1_load<N>(v, b, l, arg.src, m, R, sig);
+  const double e = dense_d1_core<N>(v, *Kc, P, b, l, arg.dt, arg.t, m, R, sig, mn, Rn, sign, v.atol[b], v.rtol[b]);
+  dense_d1_store<N>(v, b, l, arg.dst, mn, Rn, sign);
   return e;
 }
 
 // One attempted step by one wavefront; returns the normalised error norm (wave-uniform).
+// (WITH_D1 = false: the caller never sees a scalar ODE -- the device-resident controller has its own kernel for it -- and does not
+// carry that code.)
+template <bool WITH_D1>
 __device__ double dense_small_attempt(const DenseView& v, const IwpConst& K, int b, int lane, const StepArg& arg, double* lds) {
-  if (v.d == 1 && v.k <= 2 && v.n >= 3) {  // scalar ODE: n x n in registers (above)
+  if (WITH_D1 && v.d == 1 && v.k <= 2 && v.n >= 3) {  // scalar ODE: n x n in registers (above)
     switch (v.n) {
-      case 3: return dense_d1_attempt<3>(v, K, b, lane, arg);
-      case 4: return dense_d1_attempt<4>(v, K, b, lane, arg);
-      case 5: return dense_d1_attempt<5>(v, K, b, lane, arg);
-      case 6: return dense_d1_attempt<6>(v, K, b, lane, arg);
-      case 7: return dense_d1_attempt<7>(v, K, b, lane, arg);
-      case 8: return dense_d1_attempt<8>(v, K, b, lane, arg);
+      case 3: return dense_d1_attempt<3>(v, &K, b, lane, arg);
+      case 4: return dense_d1_attempt<4>(v, &K, b, lane, arg);
+      case 5: return dense_d1_attempt<5>(v, &K, b, lane, arg);
+      case 6: return dense_d1_attempt<6>(v, &K, b, lane, arg);
+      case 7: return dense_d1_attempt<7>(v, &K, b, lane, arg);
+      case 8: return dense_d1_attempt<8>(v, &K, b, lane, arg);
       default: break;
     }
   }
@@ -392,7 +424,7 @@ __global__ __launch_bounds__(64) void dense_small_step_kernel(DenseView v, const
   const int b = blockIdx.x;
   const StepArg arg = args[b];
   if (!arg.active) return;
-  const double e = dense_small_attempt(v, *Kc, b, threadIdx.x, arg, smem);
+  const double e = dense_small_attempt<true>(v, *Kc, b, threadIdx.x, arg, smem);
   if (threadIdx.x == 0) v.errnorm[b] = e;
 }
 
@@ -405,18 +437,18 @@ __device__ __forceinline__ bool small_after_attempt(TrajCtl& c, const ControlPar
     c.status = 2;
     accept = true;
   } else {
-    const double le = log(e);
+    const double le = ln::uniform(log(e));
     const double raw = cp.safety * exp(cp.n2 * c.log_prev - (cp.n1 + cp.n2) * le);
     const double factor = fmax(cp.factor_min, fmin(raw, cp.factor_max));
     if (e <= 1.0) c.log_prev = le;
-    c.dt = factor * dt;
+    c.dt = ln::uniform(factor * dt);
     accept = !(e > 1.0);
   }
   if (accept) {
     c.s_if = c.s_sf;
     c.t_if = c.t_sf;
     c.s_sf = c.s_pr;
-    c.t_sf += dt;
+    c.t_sf = ln::uniform(c.t_sf + dt);
     c.steps += 1;
     int fr = 0;
     while (fr == c.s_if || fr == c.s_sf) ++fr;
@@ -441,7 +473,7 @@ __global__ __launch_bounds__(64) void dense_small_advance_kernel(DenseView v, Tr
     if (cp.clip) dt = fmin(dt, c.t_stop - c.t_sf);
     StepArg arg;
     arg.dt = dt; arg.t = c.t_sf; arg.src = c.s_sf; arg.dst = c.s_pr; arg.active = 1; arg.pad = 0;
-    const double e = dense_small_attempt(v, *Kc, b, lane, arg, smem);
+    const double e = dense_small_attempt<false>(v, *Kc, b, lane, arg, smem);
     __threadfence_block();
     ++iters;
     small_after_attempt(c, cp, e, dt);
@@ -457,36 +489,37 @@ template <int N>
 __global__ __launch_bounds__(64) void dense_d1_advance_kernel(DenseView v, TrajCtl* __restrict__ ctl, const IwpConst* __restrict__ Kc,
                                                               ControlParams cp) {
   const int b = blockIdx.x;
-  const int lane = threadIdx.x;
+  const int l = ln::col_index<N>(threadIdx.x);
   TrajCtl c = ctl[b];
   if (c.status < 0) return;
   const IwpConst& K = *Kc;
+  D1Prior<N> P;
+  d1_load_prior<N>(Kc, P, l);
   int iters = 0;
   c.status = 0;
   const double atol = v.atol[b], rtol = v.rtol[b];
-  double cm[N], cR[N][N], csig;
-  dense_d1_load<N>(v, b, c.s_sf, cm, cR, csig);
+  double cm[N], cR[N], csig;
+  dense_d1_load<N>(v, b, l, c.s_sf, cm, cR, csig);
   while (c.t_sf + cp.numerical_zero < c.t_stop && iters < cp.max_iters) {
     double dt = c.dt;
     if (cp.clip) dt = fmin(dt, c.t_stop - c.t_sf);
-    double nm[N], nR[N][N], nsig;
-    const double e = dense_d1_core<N>(v, K, b, dt, c.t_sf, cm, cR, csig, nm, nR, nsig, atol, rtol);
+    double nm[N], nR[N], nsig;
+    const double e = dense_d1_core<N>(v, K, P, b, l, dt, c.t_sf, cm, cR, csig, nm, nR, nsig, atol, rtol);
     ++iters;
     const int dst = c.s_pr;
     if (small_after_attempt(c, cp, e, dt)) {
-      dense_d1_store<N>(v, b, lane, dst, nm, nR, nsig);
+      dense_d1_store<N>(v, b, l, dst, nm, nR, nsig);
 #pragma unroll
       for (int i = 0; i < N; ++i) {
         cm[i] = nm[i];
-#pragma unroll
-        for (int j = 0; j < N; ++j) cR[i][j] = nR[i][j];
+        cR[i] = nR[i];
       }
       csig = nsig;
     }
     if (c.status == 2) break;
   }
   if (c.status == 0) c.status = (c.t_sf + cp.numerical_zero >= c.t_stop) ? 1 : 3;
-  if (lane == 0) ctl[b] = c;
+  ctl[b] = c;
 }
 
 // Fixed grid (pnode_solve_fixed_grid, the reference's solve_fixed_grid, vdp.py:88-105) for a scalar ODE: the whole replay in ONE
@@ -498,25 +531,26 @@ template <int N>
 __global__ __launch_bounds__(64) void dense_d1_fixed_grid_kernel(DenseView v, const StepArg* __restrict__ args, const IwpConst* __restrict__ Kc,
                                                                  double* __restrict__ out, int G) {
   const int b = blockIdx.x;
-  const int lane = threadIdx.x;
+  const int l = ln::col_index<N>(threadIdx.x);
   const IwpConst& K = *Kc;
+  D1Prior<N> P;
+  d1_load_prior<N>(Kc, P, l);
   const size_t B = size_t(v.B);
-  double cm[N], cR[N][N], csig;
-  dense_d1_load<N>(v, b, args[b].dst, cm, cR, csig);
-  if (lane == 0) out[size_t(b) * G] = cm[0];
+  double cm[N], cR[N], csig;
+  dense_d1_load<N>(v, b, l, args[b].dst, cm, cR, csig);
+  out[size_t(b) * G] = cm[0];
   const double atol = v.atol[b], rtol = v.rtol[b];
 #pragma unroll 1
   for (int g = 1; g < G; ++g) {
     const StepArg a = args[size_t(g) * B + b];
-    double nm[N], nR[N][N], nsig;
-    (void)dense_d1_core<N>(v, K, b, a.dt, a.t, cm, cR, csig, nm, nR, nsig, atol, rtol);
-    if (lane == 0) out[size_t(b) * G + g] = nm[0];
-    if (g >= G - 2) dense_d1_store<N>(v, b, lane, a.dst, nm, nR, nsig);
+    double nm[N], nR[N], nsig;
+    (void)dense_d1_core<N>(v, K, P, b, l, a.dt, a.t, cm, cR, csig, nm, nR, nsig, atol, rtol);
+    out[size_t(b) * G + g] = nm[0];
+    if (g >= G - 2) dense_d1_store<N>(v, b, l, a.dst, nm, nR, nsig);
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       cm[i] = nm[i];
-#pragma unroll
-      for (int j = 0; j < N; ++j) cR[i][j] = nR[i][j];
+      cR[i] = nR[i];
     }
     csig = nsig;
   }

@@ -1,5 +1,6 @@
-// n x n algebra of the isotropic model SPREAD OVER THE LANES of a wavefront (r04; replaces the per-lane-redundant form of
-// pnode_nxn.hpp in pnode_iso.hip, which needed n^2 registers per matrix in every lane: 256 VGPRs + AGPR spills from nu = 4 on,
+// n x n algebra of the isotropic model (and of the dense model of a scalar ODE, pnode_dense_small.hip) SPREAD OVER THE LANES of a
+// wavefront (r04; replaces the per-lane-redundant form of rounds 1-3, `git show a465765:code-adaptive-prob-ode-solvers_amd/csrc/pnode_nxn.hpp`,
+// which needed n^2 registers per matrix in every lane: 256 VGPRs + AGPR spills from nu = 4 on,
 // scratch from nu = 7 on -- and one of those spills, placed by the compiler in front of the exec restore of a `lane < d` region,
 // was the memory access fault of the looped smoother kernel).
 //
@@ -19,9 +20,9 @@
 // The copies must stay IDENTICAL bit for bit: whatever enters the n x n algebra from the ODE dimensions (sums over the wavefront)
 // has to be the same in every lane (wave_sum of pnode_common.hpp; ln::uniform).
 //
-// Orthogonal triangularisations are Householder reflections (one reciprocal square root per COLUMN, the rotations of pnode_nxn.hpp
+// Orthogonal triangularisations are Householder reflections (one reciprocal square root per COLUMN, the Givens rotations of rounds 1-3
 // took one per ELEMENT), rows negated where needed so that the triangular factor has a non-negative diagonal like the one the
-// rotations gave. Follows the same reference call sites as pnode_nxn.hpp (arithmetic re-derived, oracle/pn_oracle.py is the
+// rotations gave. Follows the reference call sites below (arithmetic re-derived, oracle/pn_oracle.py is the
 // CPU restatement): /root/reference/src/odecheckpts/ivpsolvers.py:37-50.
 #pragma once
 #include <utility>
@@ -183,7 +184,7 @@ __device__ __forceinline__ void qr_square(double (&Y)[N], int l) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Time update in preconditioned coordinates (iso_time_update of pnode_nxn.hpp in the lane layout).
+// Time update in preconditioned coordinates.
 //   in : Rprev (col-lane; Sigma_prev = Rprev^T Rprev), uniform p / pinv for this dt and my lane's entries pl / pil, sigma
 //   out: Rm (col-lane, upper triangular, Sigma^- = Rm^T Rm); with COND the backward transition  x_prev | x_new ~ N(G x_new + xi,
 //        RL^T RL): G row-lane, RL col-lane (upper triangular)
