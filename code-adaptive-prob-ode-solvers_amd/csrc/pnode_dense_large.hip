@@ -171,6 +171,9 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(double* __restrict__ 
 
 static void gemm(hipStream_t s, int batch, bool transB, const Gemm& g) {
   if (g.M <= 0 || g.N <= 0 || batch <= 0) return;
+#ifdef PNODE_TIMING_BUILD
+  fprintf(stderr, "gemm M %d N %d K %d batch %d transB %d ksplit %d beta %g\n", g.M, g.N, g.K, batch, int(transB), g.ksplit, g.beta);
+#endif
   if (g.N <= 32) {
     dim3 grid(g.ksplit > 1 ? g.ksplit : (g.N + 31) / 32, (g.M + 127) / 128, batch);
     if (transB && g.K % 64 == 0)
