@@ -1246,6 +1246,19 @@ int pnode_read_checkpoint_factors(pnode_batch* h, double* out) {
   return PNODE_OK;
 }
 
+int pnode_read_checkpoint_transitions(pnode_batch* h, double* G, double* xi, double* Lam) {
+  if (!h || !G || !xi || !Lam) return fail(PNODE_EINVAL, "null argument");
+  if (h->dense || !h->iso.fixedpoint)
+    return fail(PNODE_EINVAL, "checkpoint transitions are stored by the isotropic model with a backward model (fixedpoint / smoother)");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  const size_t B = h->cfg.batch, K = h->cfg.num_checkpoints, n = h->n, d = h->cfg.d;
+  if (B * K == 0) return PNODE_OK;
+  HIP_TRY(hipMemcpy(G, h->iso.ck_G, B * K * n * n * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(xi, h->iso.ck_xi, B * K * n * d * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(Lam, h->iso.ck_Lam, B * K * n * n * sizeof(double), hipMemcpyDeviceToHost));
+  return PNODE_OK;
+}
+
 int pnode_smooth_checkpoint_means(pnode_batch* h, const int32_t* num_filled, double* out) {
   if (!h || !num_filled || !out) return fail(PNODE_EINVAL, "null argument");
   if ((h->dense && !h->dn.fixedpoint) || (!h->dense && !h->iso.fixedpoint))

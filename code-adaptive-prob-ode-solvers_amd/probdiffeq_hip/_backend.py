@@ -24,7 +24,7 @@ SYMBOLS = (
     "pnode_set_tolerances pnode_attempt_step pnode_user_extrapolate pnode_user_set_vf pnode_commit pnode_interpolate pnode_checkpoint_at_step "
     "pnode_solve_fixed_grid pnode_solve_adaptive_save_at pnode_solve_adaptive_save_at_device pnode_read_mean pnode_read_time pnode_read_output_scale pnode_read_factor "
     "pnode_read_checkpoint_means pnode_read_checkpoint_factors pnode_smooth_checkpoint_means pnode_last_step_ms pnode_set_phase_timing "
-    "pnode_last_phase_ms pnode_set_generic_path pnode_stream pnode_advance_device pnode_debug_set_lq_spin_limit pnode_phase_ms_mean pnode_sample_checkpoints_n pnode_set_smoother_pipeline"
+    "pnode_last_phase_ms pnode_set_generic_path pnode_stream pnode_advance_device pnode_debug_set_lq_spin_limit pnode_phase_ms_mean pnode_sample_checkpoints_n pnode_set_smoother_pipeline pnode_read_checkpoint_transitions"
 ).split()
 
 
@@ -110,6 +110,7 @@ def load_library():
     lib.pnode_read_factor.argtypes = [vp, C.c_int32, dp]
     lib.pnode_read_checkpoint_means.argtypes = [vp, dp]
     lib.pnode_read_checkpoint_factors.argtypes = [vp, dp]
+    lib.pnode_read_checkpoint_transitions.argtypes = [vp, dp, dp, dp]
     lib.pnode_smooth_checkpoint_means.argtypes = [vp, i32p, dp]
     lib.pnode_last_step_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.pnode_set_phase_timing.argtypes = [vp, C.c_int32]
@@ -346,6 +347,14 @@ class Batch:
         out = np.zeros((self.B, self.K, m, m))
         _check(self._lib.pnode_read_checkpoint_factors(self._h, _dp(out)))
         return out
+
+    def read_checkpoint_transitions(self):
+        """(G [B][K][n][n], xi [B][K][n][d], Lam [B][K][n][n]) of the stored backward transitions (isotropic model, fixedpoint / smoother)."""
+        G = np.zeros((self.B, self.K, self.n, self.n))
+        xi = np.zeros((self.B, self.K, self.n, self.d))
+        Lam = np.zeros((self.B, self.K, self.n, self.n))
+        _check(self._lib.pnode_read_checkpoint_transitions(self._h, _dp(G), _dp(xi), _dp(Lam)))
+        return G, xi, Lam
 
     def smooth_checkpoint_means(self, num_filled):
         nf = self._slots(num_filled)

@@ -1,0 +1,108 @@
+"""A property of the reference's algorithm that explains a precision difference at nu = 8: the fixed-point
+smoother's stored backward transition x(c_{k-1}) | x(c_k) is formed from the piece (t0 -> c_k) of the step that oversteps the
+checkpoint c_k (/root/reference/src/odecheckpts/ivpsolvers.py:71-77 -> probdiffeq's strategy_fixedpoint interpolation, restated
+in oracle/pn_oracle.py interpolate()). When c_k falls very close behind the step start t0, the process noise of that piece is
+(c_k - t0)^(2 nu + 1) small against the filter covariance, the stacked QR of revert_conditional loses the direction the noise-free
+measurement removed, and the gain it returns has entries 1e8 instead of 1 (the exact gain, computed here in rational arithmetic,
+is A(dt)^{-1} to 1e-9). G x + xi then cancels 8 digits at every earlier checkpoint. CPU only; the oracle is the checker."""
+
+from fractions import Fraction
+from math import factorial
+
+import numpy as np
+import pn_oracle as po
+import scipy.integrate
+from helpers import oracle_problem
+
+NU = 8
+TOL = 1e-9
+
+
+def _pleiades():
+    from odecheckpts import ivps
+    from probdiffeq_hip import taylor
+
+    vf, u0, _ = ivps.pleiades_2nd()
+    vf1, u01, _, _ = ivps.pleiades_1st()
+    tcs = taylor.odejet_padded_scan(vf, [u0[0][None], u0[1][None]], num=NU - 1)
+    return vf, vf1, u01, tcs
+
+
+def _run(vf, tcs, save_at, record=None):
+    cfg = po.SolverConfig(nu=NU, model="isotropic", correction="ts0", strategy="fixedpoint", calibration="dynamic")
+    rt = 10.0 * TOL
+    original = po.interpolate
+
+    def spy(cfg_, prob, ast, t):
+        if record is not None:
+            record.append((t, ast.interp_from.t, ast.step_from.t, ast.interp_from.chol.copy(), ast.step_from.output_scale))
+        return original(cfg_, prob, ast, t)
+
+    po.interpolate = spy
+    try:
+        sol = po.solve_adaptive_save_at(cfg, po.AdaptiveConfig(1e-3 * rt, rt), oracle_problem(vf), po.initial_state(cfg, [c[0] for c in tcs], 0.0),
+                                        save_at, 0.1)
+    finally:
+        po.interpolate = original
+    return cfg, sol, po.markov_marginals_reverse(cfg, sol)[:, 0]
+
+
+def _exact_gain(chol, dt, sigma):
+    """Sigma A^T (A Sigma A^T + sigma^2 Q)^{-1} for the IWP(nu) transition over dt, in rational arithmetic."""
+    n = NU + 1
+    c = [[Fraction(float(chol[i, j])) for j in range(n)] for i in range(n)]
+    s = [[sum(c[i][k] * c[j][k] for k in range(n)) for j in range(n)] for i in range(n)]
+    h, s2 = Fraction(float(dt)), Fraction(float(sigma)) ** 2
+    a = [[h ** (j - i) / factorial(j - i) if j >= i else Fraction(0) for j in range(n)] for i in range(n)]
+    q = [[s2 * h ** (2 * NU + 1 - i - j) / ((2 * NU + 1 - i - j) * factorial(NU - i) * factorial(NU - j)) for j in range(n)] for i in range(n)]
+    mm = lambda x, y: [[sum(x[i][k] * y[k][j] for k in range(n)) for j in range(n)] for i in range(n)]
+    tr = lambda x: [[x[j][i] for j in range(n)] for i in range(n)]
+    sat = mm(s, tr(a))
+    pred = mm(a, sat)
+    aug = [[pred[i][j] + q[i][j] for j in range(n)] + tr(sat)[i] for i in range(n)]
+    for col in range(n):
+        piv = next(r for r in range(col, n) if aug[r][col] != 0)
+        aug[col], aug[piv] = aug[piv], aug[col]
+        inv = 1 / aug[col][col]
+        aug[col] = [x * inv for x in aug[col]]
+        for r in range(n):
+            if r != col and aug[r][col] != 0:
+                f = aug[r][col]
+                aug[r] = [x - f * y for x, y in zip(aug[r], aug[col])]
+    return np.array([[float(aug[j][n + i]) for j in range(n)] for i in range(n)])
+
+
+def test_a_checkpoint_close_behind_a_step_start_costs_the_reference_algorithm_eight_digits():
+    vf, vf1, u01, tcs = _pleiades()
+    grid = np.linspace(0.0, 3.0, 50)[:8]  # the grid of experiment 3 (run_harder.py), first 8 points
+    truth = lambda xs: scipy.integrate.solve_ivp(lambda t, y: vf1(y), (0.0, xs[-1]), u01[0], method="DOP853", atol=1e-13, rtol=1e-13, t_eval=xs).y.T[:, :14]
+
+    rec = []
+    _, sol, sm = _run(vf, tcs, grid, rec)
+    err = np.max(np.abs(sm - truth(grid)), axis=1)
+    assert err.max() < 1e-10, err  # the experiment's own grid: no checkpoint closer than 0.06 of a step behind a step start
+    assert min((t - t0) / (t1 - t0) for t, t0, t1, _, _ in rec) > 0.05
+
+    # move checkpoint 5 to 1e-4 behind the start of the step that oversteps it
+    t, t0, t1, _, _ = rec[4]
+    assert t == grid[5]
+    moved = grid.copy()
+    moved[5] = t0 + 9e-5
+    rec2 = []
+    cfg, sol2, sm2 = _run(vf, tcs, moved, rec2)
+    assert np.array_equal(sol2.num_steps[:5], sol.num_steps[:5])
+    err2 = np.max(np.abs(sm2 - truth(moved)), axis=1)
+    assert err2[5:].max() < 1e-10, err2  # from the moved checkpoint on: as before
+    assert err2[1:5].min() > 1e-8, err2  # every checkpoint before it: eight digits gone
+    big = np.max(np.abs(sol2.states[5].cond.G[0, 2:]))
+    assert big > 1e6, big  # the stored transition x(c_4) | x(c_5): position row, acceleration column
+
+    # the gain of the piece (t0 -> c_5) in exact arithmetic is harmless: the loss is the QR's, not the model's
+    tm, t0m, _, chol0, sigma = rec2[4]
+    assert tm == moved[5] and abs((tm - t0m) - 9e-5) < 1e-12
+    g = _exact_gain(chol0, tm - t0m, sigma)
+    p, p_inv = po.iwp_preconditioner(tm - t0m, NU)
+    scaled = p_inv[:, None] * g * p[None, :]
+    assert np.max(np.abs(scaled)) < 100.0
+    _, (g_qr, _) = po._extrapolate_cov(cfg, chol0, p, p_inv, sigma, 14, True)
+    assert np.max(np.abs(p_inv[:, None] * g_qr * p[None, :] - scaled)) > 1e6

@@ -189,3 +189,34 @@ def test_checkpoints_inside_the_controller_kernel(hip_lib, N, strategy):
         assert np.array_equal(steps, host.num_steps) and np.array_equal(attempts, host.num_attempts)
     finally:
         batch.close()
+
+
+@pytest.mark.parametrize("nu", [3, 5])
+def test_stored_backward_transitions_vs_oracle(hip_lib, nu):
+    """pnode_read_checkpoint_transitions: the transitions x(c_{k-1}) | x(c_k) ~ N(G x + xi, Lam^T Lam) the fixed-point smoother
+    stores -- probdiffeq's `posterior.conditional`, /root/reference/src/odecheckpts/ivpsolvers.py:80 -- entry by entry against the
+    oracle's (restricted three-body problem in second-order form, isotropic EKF0). Entry 0 is the transition to the initial time from the first stored point, which is
+    the initial time itself: G = 0, xi = the initial mean."""
+    from odecheckpts import ivps
+
+    vf, (u0, du0), (t0, _) = ivps.three_body_restricted()
+    impl.select("isotropic", ode_shape=(vf.d,))
+    solver = _solver(nu, "fixedpoint", ode_order=2)
+    tcs = taylor.odejet_padded_scan(vf, [u0[None], du0[None]], num=nu - 1)
+    init = solver.initial_condition(tcs, 1.0)
+    save_at = np.linspace(t0, t0 + 1.5, 7)
+    tol = 1e-5
+    sol = ivpsolve.solve_adaptive_save_at(vf, init, save_at=save_at, dt0=0.01, adaptive_solver=ivpsolve.adaptive(solver, atol=1e-3 * tol, rtol=tol))
+    osol, sm = _oracle_fp(vf, tcs, 0, nu, 1e-3 * tol, tol, save_at, 0.01)
+    assert np.array_equal(sol.num_steps[0], osol.num_steps) and osol.num_steps[-1] > 30
+    assert relmax(sol.u[0], sm) < 1e-9
+    G, xi, Lam = sol.posterior.batch.read_checkpoint_transitions()
+    K = len(save_at)
+    assert G.shape[:2] == (1, K) and xi.shape == (1, K, nu + 1, vf.d)
+    assert np.all(G[0, 0] == 0.0) and np.array_equal(xi[0, 0], np.stack([c[0] for c in tcs]))
+    for c in range(1, K):
+        oc = osol.states[c].cond
+        assert relmax(G[0, c], oc.G) < 1e-7, c
+        assert relmax(xi[0, c], oc.xi) < 1e-7, c
+        assert np.all(np.diag(Lam[0, c]) >= 0.0) and np.all(np.tril(Lam[0, c], -1) == 0.0)
+        assert relmax(Lam[0, c].T @ Lam[0, c], oc.Lam @ oc.Lam.T) < 1e-6, c
