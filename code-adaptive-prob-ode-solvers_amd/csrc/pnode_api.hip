@@ -1248,14 +1248,19 @@ int pnode_read_checkpoint_factors(pnode_batch* h, double* out) {
 
 int pnode_read_checkpoint_transitions(pnode_batch* h, double* G, double* xi, double* Lam) {
   if (!h || !G || !xi || !Lam) return fail(PNODE_EINVAL, "null argument");
-  if (h->dense || !h->iso.fixedpoint)
-    return fail(PNODE_EINVAL, "checkpoint transitions are stored by the isotropic model with a backward model (fixedpoint / smoother)");
+  if (h->dense ? !h->dn.fixedpoint : !h->iso.fixedpoint)
+    return fail(PNODE_EINVAL, "checkpoint transitions are stored with a backward model only (strategy fixedpoint / smoother)");
   HIP_TRY(hipSetDevice(h->cfg.device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
   const size_t B = h->cfg.batch, K = h->cfg.num_checkpoints, n = h->n, d = h->cfg.d;
   if (B * K == 0) return PNODE_OK;
-  HIP_TRY(hipMemcpy(G, h->iso.ck_G, B * K * n * n * sizeof(double), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(xi, h->iso.ck_xi, B * K * n * d * sizeof(double), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(Lam, h->iso.ck_Lam, B * K * n * n * sizeof(double), hipMemcpyDeviceToHost));
+  const size_t m = h->dense ? n * d : n, nx = n * d;  // dense: D x D matrices over the flattened state (index i d + j)
+  const double* sG = h->dense ? h->dn.ck_G : h->iso.ck_G;
+  const double* sx = h->dense ? h->dn.ck_xi : h->iso.ck_xi;
+  const double* sL = h->dense ? h->dn.ck_Lam : h->iso.ck_Lam;
+  HIP_TRY(hipMemcpy(G, sG, B * K * m * m * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(xi, sx, B * K * nx * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(Lam, sL, B * K * m * m * sizeof(double), hipMemcpyDeviceToHost));
   return PNODE_OK;
 }
 

@@ -349,10 +349,13 @@ class Batch:
         return out
 
     def read_checkpoint_transitions(self):
-        """(G [B][K][n][n], xi [B][K][n][d], Lam [B][K][n][n]) of the stored backward transitions (isotropic model, fixedpoint / smoother)."""
-        G = np.zeros((self.B, self.K, self.n, self.n))
-        xi = np.zeros((self.B, self.K, self.n, self.d))
-        Lam = np.zeros((self.B, self.K, self.n, self.n))
+        """The stored backward transitions x_{c-1} | x_c ~ N(G x + xi, Lambda) (pnode_read_checkpoint_transitions).
+        isotropic: G (B, K, n, n), xi (B, K, n, d), Lam (B, K, n, n) upper triangular, Lambda = Lam^T Lam (x) I_d;
+        dense: G (B, K, D, D), xi (B, K, D), Lam (B, K, D, D) lower triangular, Lambda = Lam Lam^T."""
+        m = self.D if self.model == "dense" else self.n
+        G = np.zeros((self.B, self.K, m, m))
+        xi = np.zeros((self.B, self.K, self.D) if self.model == "dense" else (self.B, self.K, self.n, self.d))
+        Lam = np.zeros((self.B, self.K, m, m))
         _check(self._lib.pnode_read_checkpoint_transitions(self._h, _dp(G), _dp(xi), _dp(Lam)))
         return G, xi, Lam
 

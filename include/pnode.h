@@ -187,10 +187,12 @@ int pnode_read_checkpoint_means(pnode_batch* h, double* out);
  * model and for interpolated checkpoints, a general square factor where a checkpoint coincides with a step; m = nu+1 for the isotropic
  * model, Sigma = R^T R (x) I_d; m = (nu+1) d for the dense filter created with PNODE_FLAG_CHECKPOINT_FACTORS). */
 int pnode_read_checkpoint_factors(pnode_batch* h, double* out);
-/* Isotropic model with a backward model (strategy_fixedpoint, strategy_smoother): the stored transitions themselves,
- * x_{c-1} | x_c ~ N(G_c x_c + xi_c, (Lam_c^T Lam_c) (x) I_d) for store entry c (x_{-1}: the initial time) -- what probdiffeq's
- * solution object carries as `posterior.conditional` (src/odecheckpts/ivpsolvers.py:80 reads it through markov_select_terminal).
- * G [B][K][nu+1][nu+1], xi [B][K][nu+1][d], Lam [B][K][nu+1][nu+1] (upper triangular factor, non-negative diagonal). */
+/* Handles with a backward model (strategy_fixedpoint, strategy_smoother): the stored transitions themselves,
+ * x_{c-1} | x_c ~ N(G_c x_c + xi_c, Lambda_c) for store entry c (x_{-1}: the initial time) -- what probdiffeq's solution object
+ * carries as `posterior.conditional` (src/odecheckpts/ivpsolvers.py:80 reads it through markov_select_terminal).
+ * Isotropic model: G [B][K][nu+1][nu+1], xi [B][K][nu+1][d], Lam [B][K][nu+1][nu+1] an UPPER triangular factor with non-negative
+ * diagonal, Lambda = (Lam^T Lam) (x) I_d. Dense model (D = (nu+1) d, state index i d + j): G [B][K][D][D], xi [B][K][D],
+ * Lam [B][K][D][D] a LOWER triangular factor, Lambda = Lam Lam^T (the factors as the two models' kernels keep them). */
 int pnode_read_checkpoint_transitions(pnode_batch* h, double* G, double* xi, double* Lam);
 /* Backward pass over the stored checkpoint transitions (fixedpoint only):
  * stats.markov_select_terminal + stats.markov_marginals(reverse=True) — ivpsolvers.py:80-81.

@@ -638,6 +638,16 @@ def test_dense_fixedpoint_smoother_vs_oracle(hip_lib, case, monkeypatch):
     sm = po.markov_marginals_reverse(cfg, osol)
     assert relmax(sol.u, sm[:, 0]) < 1e-8                 # backward pass over the stored transitions
     assert relmax(sol.posterior.means[0, :, 1], sm[:, 1]) < 1e-6
+    # the stored transitions themselves (probdiffeq's posterior.conditional): pnode_read_checkpoint_transitions, dense layout
+    G, xi, Lam = sol.posterior.batch.read_checkpoint_transitions()
+    D = (nu + 1) * vf.d
+    K = len(save_at) - 1  # store entry c: x(save_at[c]) | x(save_at[c + 1])
+    assert G.shape == (1, K, D, D) and xi.shape == (1, K, D)
+    for c in range(K):
+        oc = osol.states[c + 1].cond
+        assert relmax(G[0, c], oc.G) < 1e-6, c
+        assert relmax(xi[0, c], oc.xi) < 1e-6, c
+        assert relmax(Lam[0, c] @ Lam[0, c].T, oc.Lam @ oc.Lam.T) < 1e-5, c
 
 
 @pytest.mark.parametrize("model", ["isotropic", "dense"])

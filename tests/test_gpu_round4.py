@@ -195,8 +195,7 @@ def test_checkpoints_inside_the_controller_kernel(hip_lib, N, strategy):
 def test_stored_backward_transitions_vs_oracle(hip_lib, nu):
     """pnode_read_checkpoint_transitions: the transitions x(c_{k-1}) | x(c_k) ~ N(G x + xi, Lam^T Lam) the fixed-point smoother
     stores -- probdiffeq's `posterior.conditional`, /root/reference/src/odecheckpts/ivpsolvers.py:80 -- entry by entry against the
-    oracle's (restricted three-body problem in second-order form, isotropic EKF0). Entry 0 is the transition to the initial time from the first stored point, which is
-    the initial time itself: G = 0, xi = the initial mean."""
+    oracle's (restricted three-body problem in second-order form, isotropic EKF0)."""
     from odecheckpts import ivps
 
     vf, (u0, du0), (t0, _) = ivps.three_body_restricted()
@@ -211,11 +210,12 @@ def test_stored_backward_transitions_vs_oracle(hip_lib, nu):
     assert np.array_equal(sol.num_steps[0], osol.num_steps) and osol.num_steps[-1] > 30
     assert relmax(sol.u[0], sm) < 1e-9
     G, xi, Lam = sol.posterior.batch.read_checkpoint_transitions()
-    K = len(save_at)
-    assert G.shape[:2] == (1, K) and xi.shape == (1, K, nu + 1, vf.d)
-    assert np.all(G[0, 0] == 0.0) and np.array_equal(xi[0, 0], np.stack([c[0] for c in tcs]))
-    for c in range(1, K):
-        oc = osol.states[c].cond
+    K = len(save_at) - 1  # store entry c: x(save_at[c]) | x(save_at[c + 1])
+    assert G.shape == (1, K, nu + 1, nu + 1) and xi.shape == (1, K, nu + 1, vf.d)
+    # the first transition leaves a state without uncertainty: G = 0, xi = the initial mean
+    assert np.all(G[0, 0] == 0.0) and np.allclose(xi[0, 0], np.stack([c[0] for c in tcs]), rtol=1e-14, atol=0)
+    for c in range(K):
+        oc = osol.states[c + 1].cond
         assert relmax(G[0, c], oc.G) < 1e-7, c
         assert relmax(xi[0, c], oc.xi) < 1e-7, c
         assert np.all(np.diag(Lam[0, c]) >= 0.0) and np.all(np.tril(Lam[0, c], -1) == 0.0)
