@@ -1378,12 +1378,13 @@ int pnode_last_step_ms(pnode_batch* h, float* ms_out) {
 
 int pnode_set_generic_path(pnode_batch* h, int32_t enabled) {
   if (!h) return fail(PNODE_EINVAL, "null handle");
-  if (enabled == 2 && !dense_large_supported(h->dn)) return fail(PNODE_EINVAL, "the large-D path does not support this shape");
+  if ((enabled == 2 || enabled == 4) && !dense_large_supported(h->dn)) return fail(PNODE_EINVAL, "the large-D path does not support this shape");
   if (h->stepped)
     return fail(PNODE_ESTATE, "the device path is chosen before the first step (the paths store the state factor in different layouts)");
   h->dn.force_generic = enabled == 1 || h->dn.fixedpoint;  // the register-resident MFMA kernels have no extra-row LQ
   h->dn.user_generic = enabled == 1;
-  h->dn.force_large = enabled == 2;
+  h->dn.force_large = enabled == 2 || enabled == 4;
+  h->dn.gemm_tile64 = enabled == 4;
   h->dn.lq_two_launch = enabled == 3;
   return PNODE_OK;
 }

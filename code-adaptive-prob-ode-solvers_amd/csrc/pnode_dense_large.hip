@@ -156,6 +156,147 @@ __global__ __launch_bounds__(256) void gemm_kernel(Gemm g) {
       }
 }
 
+// The same product for the square shapes of the blocked LQ and of the measurement update (M, N >= 128, K >= 64): 128 x 128 tile per
+// workgroup, 64 x 64 (4 x 4 MFMA tiles, 16 accumulators) per wavefront -- one LDS operand read per two MFMAs instead of one per
+// MFMA, half the global traffic per flop of the 64 x 64 tile -- and the k-tiles double-buffered in LDS: ONE barrier per k-tile, 64
+// MFMAs (4 096 matrix-pipe cycles) per wavefront between two barriers instead of 16. Tile it + 1 is written to the other LDS buffer
+// and the global loads of tile it + 2 are issued in front of the MFMAs of tile it. Element by element the same sums in the same order as
+// gemm_kernel (k ascending, four per MFMA): the two kernels give identical bits.
+template <bool TB>
+__global__ __launch_bounds__(256, 2) void gemm128_kernel(Gemm g) {
+  constexpr int BM = 128, BN = 128, KS = 16, LDAS = KS + 1;
+  constexpr int LDBS = TB ? KS + 1 : BN + 16;
+  constexpr int ASZ = BM * LDAS, BSZ = TB ? BN * LDBS : KS * LDBS;
+  __shared__ double As[2 * ASZ];
+  __shared__ double Bs[2 * BSZ];
+  // Workgroup -> (trajectory, tile): consecutive workgroup ids go to consecutive XCDs (eight, each with its own L2), so with the plain
+  // (x, y, z) order the eight column tiles that read the same 128 rows of A would sit in eight different L2s. All tiles of a trajectory
+  // go to ONE XCD instead (id % 8 picks the XCD, trajectories are dealt round-robin to the XCDs): A and B of a trajectory are fetched
+  // into one L2 once per pass over k.
+  const int tx = (g.N + BN - 1) / BN, ty = (g.M + BM - 1) / BM, tiles = tx * ty;
+  int b, tile;
+  {
+    const int id = blockIdx.x, nb = gridDim.x / tiles;
+    if (nb % 8 == 0) {
+      const int slot = id >> 3;
+      b = (slot / tiles) * 8 + (id & 7);
+      tile = slot % tiles;
+    } else {
+      b = id / tiles;
+      tile = id % tiles;
+    }
+  }
+  if (g.act && !g.act[b]) return;
+  const int m0 = (tile / tx) * BM, n0 = (tile % tx) * BN;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, gq = lane >> 4;
+  const int wm = w >> 1, wn = w & 1;
+  const double* A = g.A + (g.offA ? g.offA[b] : long(b) * g.sA);
+  const double* Bm = g.B + (g.offB ? g.offB[b] : long(b) * g.sB);
+  const double4_t zero4 = {0.0, 0.0, 0.0, 0.0};
+  double4_t acc[4][4];
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = zero4;
+  double4_t ra[2], rb[2];
+  const int lrow = tid >> 2, lc4 = (tid & 3) * 4;  // A tile / transposed B tile: 64 rows x 16 per pass, two passes
+  const int nkr = tid >> 5, nc4 = (tid & 31) * 4;  // B tile (not transposed): 8 rows x 128 per pass, two passes
+  // Clamped addresses, unconditional loads; the values are masked when they are WRITTEN to LDS, a k-tile later -- a mask next to
+  // the load would make the wavefront wait for it in front of the MFMAs it is meant to hide behind.
+  bool oka[2], okb[2];
+  const double* pa[2];
+  const double* pb[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int gr = m0 + p * 64 + lrow;
+    oka[p] = gr < g.M;
+    pa[p] = A + long(oka[p] ? gr : g.M - 1) * g.lda + lc4;
+    if (TB) {
+      const int gn = n0 + p * 64 + lrow;
+      okb[p] = gn < g.N;
+      pb[p] = Bm + long(okb[p] ? gn : g.N - 1) * g.ldb + lc4;
+    } else {
+      okb[p] = n0 + nc4 < g.N;
+      pb[p] = Bm + long(p * 8 + nkr) * g.ldb + (okb[p] ? n0 + nc4 : g.N - 4);
+    }
+  }
+  auto fetch = [&](int kk) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      ra[p] = *reinterpret_cast<const double4_t*>(pa[p] + kk);
+      rb[p] = *reinterpret_cast<const double4_t*>(pb[p] + (TB ? long(kk) : long(kk) * g.ldb));
+    }
+  };
+  auto stash = [&](int buf) {
+    double* as = As + buf * ASZ;
+    double* bs = Bs + buf * BSZ;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const double4_t va = oka[p] ? ra[p] : zero4, vb = okb[p] ? rb[p] : zero4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) as[(p * 64 + lrow) * LDAS + lc4 + q] = va[q];
+      if (TB) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bs[(p * 64 + lrow) * LDBS + lc4 + q] = vb[q];
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bs[(p * 8 + nkr) * LDBS + nc4 + q] = vb[q];
+      }
+    }
+  };
+  const int nk = g.K / KS;
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  if (nk > 1) fetch(KS);
+  for (int it = 0; it < nk; ++it) {
+    // tile it + 1 (in registers since the previous iteration) goes to the other buffer -- every wavefront finished reading that
+    // buffer before the barrier that ended the previous iteration -- and the loads of tile it + 2 start: both in front of the MFMAs
+    if (it + 1 < nk) {
+      stash((it + 1) & 1);
+      if (it + 2 < nk) fetch((it + 2) * KS);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const double* as = As + (it & 1) * ASZ;
+    const double* bs = Bs + (it & 1) * BSZ;
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {
+      double a[4], bb[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        a[t] = as[(wm * 64 + t * 16 + r) * LDAS + k4 * 4 + gq];
+        bb[t] = TB ? bs[(wn * 64 + t * 16 + r) * LDBS + k4 * 4 + gq] : bs[(k4 * 4 + gq) * LDBS + wn * 64 + t * 16 + r];
+      }
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = LG_MFMA(a[tm], bb[tn], acc[tm][tn]);
+    }
+    __syncthreads();
+  }
+  const double* C0 = g.C0 ? g.C0 + long(b) * g.sC0 : nullptr;
+  double* C = g.C + (g.offC ? g.offC[b] : long(b) * g.sC);
+  // epilogue by tile rows, loads of a tile row before its stores (C0 may alias C element by element)
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm) {
+    double4_t c0v[4];
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = m0 + wm * 64 + tm * 16 + 4 * q + gq, col = n0 + wn * 64 + tn * 16 + r;
+        c0v[tn][q] = (C0 && row < g.M && col < g.N) ? C0[long(row) * g.ldc0 + col] : 0.0;
+      }
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = m0 + wm * 64 + tm * 16 + 4 * q + gq, col = n0 + wn * 64 + tn * 16 + r;
+        if (row < g.M && col < g.N) C[long(row) * g.ldc + col] = fma(g.beta, c0v[tn][q], g.alpha * acc[tm][tn][q]);
+      }
+  }
+}
+
 // P0 += P1 + ... (fixed order): the K-slices of a split skinny GEMM
 __global__ __launch_bounds__(256) void sum_partials_kernel(double* __restrict__ C, long sC, long sPart, int count, int nparts,
                                                            const int32_t* __restrict__ act) {
@@ -169,6 +310,8 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(double* __restrict__ 
   }
 }
 
+// pnode_set_generic_path(h, 4) pins the 64 x 64 tile (A/B partner of gemm128_kernel); set by the entry points below from the handle
+static thread_local bool gemm_tile128 = true;
 static void gemm(hipStream_t s, int batch, bool transB, const Gemm& g) {
   if (g.M <= 0 || g.N <= 0 || batch <= 0) return;
 #ifdef PNODE_TIMING_BUILD
@@ -182,6 +325,17 @@ static void gemm(hipStream_t s, int batch, bool transB, const Gemm& g) {
       hipLaunchKernelGGL((gemm_kernel<true, 4, 1, 1>), grid, dim3(256), 0, s, g);
     else
       hipLaunchKernelGGL((gemm_kernel<false, 4, 1, 1>), grid, dim3(256), 0, s, g);
+  } else if (gemm_tile128 && g.ksplit <= 1 && g.M >= 128 && g.N >= 128 && g.K >= 512 &&
+             long((g.M + 127) / 128) * ((g.N + 127) / 128) * batch >= 256) {
+    // Long inner dimension only (measured at D = 1024, B = 64, profiles/r04_gemm_tiles.txt): 1024 x 256 x 1024 goes from 55 to 62 TFLOP/s,
+    // while the rank-128 / rank-256 updates of the blocked LQ (K <= 256, bound by the traffic of C: 16 flops per byte) lose 12 % on the
+    // large tile, whose two workgroups per CU overlap the epilogue of one tile with the MFMAs of the next less well than eight do.
+    // (The choice depends on the shape and on the batch size, the bits do not: see gemm128_kernel.)
+    dim3 grid(((g.N + 127) / 128) * ((g.M + 127) / 128) * batch);
+    if (transB)
+      hipLaunchKernelGGL((gemm128_kernel<true>), grid, dim3(256), 0, s, g);
+    else
+      hipLaunchKernelGGL((gemm128_kernel<false>), grid, dim3(256), 0, s, g);
   } else {
     dim3 grid((g.N + 63) / 64, (g.M + 63) / 64, batch);
     if (transB)
@@ -933,11 +1087,15 @@ static void blocked_lq(const DenseView& v, int rows_total, hipStream_t s) {
 
 }  // namespace lg
 
-void dense_large_lq(const DenseView& v, int rows_total, hipStream_t s) { lg::blocked_lq(v, rows_total, s); }
+void dense_large_lq(const DenseView& v, int rows_total, hipStream_t s) {
+  lg::gemm_tile128 = !v.gemm_tile64;
+  lg::blocked_lq(v, rows_total, s);
+}
 
 // After the 2D-row LQ of a predict: G_p = C21_p (L^-_p)^-1 (blocked right triangular solve), plain coordinates,
 // xi, merge with the running transition, and the LQ of the merged noise stack [Lam0 | G0 Lam] (rows 0..D-1 of R / M).
 void dense_large_fp_backward(const DenseView& v, const FpArg* fa, const IwpConst* K, hipStream_t s) {
+  lg::gemm_tile128 = !v.gemm_tile64;
   using namespace lg;
   const int B = v.B, D = v.D;
   const long DD = long(D) * D, sDD = 2 * DD;
@@ -978,6 +1136,7 @@ bool dense_use_large(const DenseView& v) {
 }
 
 void dense_large_launch_step(const DenseView& v, const StepArg* args, const IwpConst* K, hipStream_t s, const PhaseEvents* ev) {
+  lg::gemm_tile128 = !v.gemm_tile64;
   using namespace lg;
   auto mark = [&](int i) {
     if (ev) (void)hipEventRecord(ev->ev[i], s);

@@ -90,6 +90,7 @@ struct DenseView {
   double* ck_Lam;   // [B][K][D][D]
   // large-D path (pnode_dense_large.hip): panel scratch of the blocked LQ and per-trajectory output offsets
   int force_large;  // 1: take the large-D path whenever it supports the shape (A/B testing at small D)
+  int gemm_tile64;  // 1: the batched GEMMs of the large-D path use the 64 x 64 tile only (pnode_set_generic_path(h, 4): A/B partner of the 128 x 128 tile)
   double* lgG;      // [B][mr_rows*D][128]
   double* lgW;      // [B][mr_rows*D][128]
   double* lgTf;     // [B][4][32][32]  panel factors of the current outer block

@@ -225,6 +225,7 @@ int pnode_last_step_ms(pnode_batch* h, float* ms_out);
  * kernels otherwise), 1 = generic kernels, 2 = large-D kernels (PNODE_EINVAL if the shape is not supported there),
  * 3 = MFMA kernels with the two-launch LQ (32-row passes, csrc/pnode_dense_mfma.hip) instead of the one-launch LQ with
  * overlapping 64-row passes (csrc/pnode_dense_lq4.hip), which is what 0 selects for (nu+1)*d = 128, 192, 256.
+ * 4 = large-D kernels with every batched GEMM on the 64 x 64 tile (the 128 x 128 double-buffered tile of r04 switched off; identical bits).
  * The choice must be made before the first step after pnode_set_initial (PNODE_ESTATE afterwards): the paths keep the state
  * factor in different layouts.
  * No environment variable influences the library: the choice is per handle, through this call only. */
