@@ -136,7 +136,6 @@ struct pnode_batch {
   int n = 0, D = 0;
   bool dense = false;
   hipStream_t stream = nullptr;
-  LargeSide* large_side = nullptr;  // second stream + events of the large-D path's look-ahead (dense handles it supports)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   PhaseEvents phase{};
   bool phase_timing = false;
@@ -205,14 +204,6 @@ int pnode_destroy(pnode_batch* h) {
   for (auto& pe : h->phase_pool)
     for (auto& e : pe.ev)
       if (e) (void)hipEventDestroy(e);
-  if (h->large_side) {
-    for (auto& e : h->large_side->ready)
-      if (e) (void)hipEventDestroy(e);
-    for (auto& e : h->large_side->done)
-      if (e) (void)hipEventDestroy(e);
-    if (h->large_side->stream) (void)hipStreamDestroy(h->large_side->stream);
-    delete h->large_side;
-  }
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return PNODE_OK;
@@ -402,18 +393,7 @@ int pnode_create(const pnode_config* cfg, pnode_batch** out) {
         ALLOC(v.lgW, B * v.mr_rows * D * 128);
         ALLOC(v.lgTf, B * 4 * 32 * 32);
         ALLOC(v.lgGram, B * 128 * 128);
-        ALLOC(v.lgTfo, 2 * B * 128 * 128);
-        {  // second stream + events of the blocked LQ's look-ahead (pnode_dense_large.hip); destroyed with the handle
-          LargeSide* sd = new LargeSide();
-          h->large_side = sd;
-          // lowest priority: its streaming GEMMs must not keep the workgroups of the panel chain (the handle's stream) waiting for a CU
-          int prio_least = 0, prio_greatest = 0;
-          HIP_TRY_H(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-          HIP_TRY_H(hipStreamCreateWithPriority(&sd->stream, hipStreamNonBlocking, prio_least));
-          for (auto& e : sd->ready) HIP_TRY_H(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-          for (auto& e : sd->done) HIP_TRY_H(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-          v.side = sd;
-        }
+        ALLOC(v.lgTfo, B * 128 * 128);
         ALLOC(v.lgOff, B);
         if (v.fixedpoint) {
           ALLOC(v.lgMaskMerge, B);
@@ -1398,15 +1378,13 @@ int pnode_last_step_ms(pnode_batch* h, float* ms_out) {
 
 int pnode_set_generic_path(pnode_batch* h, int32_t enabled) {
   if (!h) return fail(PNODE_EINVAL, "null handle");
-  if ((enabled == 2 || enabled == 4 || enabled == 5) && !dense_large_supported(h->dn))
-    return fail(PNODE_EINVAL, "the large-D path does not support this shape");
+  if ((enabled == 2 || enabled == 4) && !dense_large_supported(h->dn)) return fail(PNODE_EINVAL, "the large-D path does not support this shape");
   if (h->stepped)
     return fail(PNODE_ESTATE, "the device path is chosen before the first step (the paths store the state factor in different layouts)");
   h->dn.force_generic = enabled == 1 || h->dn.fixedpoint;  // the register-resident MFMA kernels have no extra-row LQ
   h->dn.user_generic = enabled == 1;
-  h->dn.force_large = enabled == 2 || enabled == 4 || enabled == 5;
+  h->dn.force_large = enabled == 2 || enabled == 4;
   h->dn.gemm_tile64 = enabled == 4;
-  h->dn.lq_sequential = enabled == 5;
   h->dn.lq_two_launch = enabled == 3;
   return PNODE_OK;
 }

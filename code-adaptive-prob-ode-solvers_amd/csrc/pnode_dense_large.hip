@@ -1005,43 +1005,12 @@ static void launch_panel(const DenseView& v, int p0, double* Tf, int tf_stride, 
 // Two levels: 32-row panels are applied inside their 128-row outer block only; the outer block's aggregated reflector
 // (Y = 128 scaled rows, 128 x 128 factor) then updates all rows below in one pass: G = T[:, blk] + Mt V^T, W = G Tf,
 // T[:, blk] -= W, Mt -= W V  -- a quarter of the trailing-matrix traffic of panel-by-panel updates.
-// Look-ahead (r04, v.side != nullptr): the update of outer block i is split into the 128 rows of outer block i + 1 (on the handle's
-// stream) and the rows below them (on a second stream); the four panel kernels of block i + 1 and their launch-sized products -- a
-// latency chain that occupies a quarter of the CUs -- then run beside the streaming update of the rows below instead of after it.
-// Same kernels on the same operands in an order that respects every dependency: the bits do not change.
-//   stream s : P_0 F_0 . A_0 P_1 F_1 [wait B_0] A_1 P_2 F_2 [wait B_1] A_2 ...      P: panels of a block, F: its aggregated factor,
-//   stream s2:      [wait F_0] B_0 ...... [wait F_1] B_1 ...... [wait F_2] B_2 ...  A / B: update of the next block's rows / of the rest
-static void outer_update(const DenseView& v, int rows_total, int o0, int OB, int r0, int rows, const double* Tfo, hipStream_t s) {
-  if (rows <= 0) return;
-  const int B = v.B, D = v.D;
-  const long sDD = long(v.mr_rows) * D * D, sG = long(rows_total) * 128, sT = 128 * 128;
-  const long loc = long(r0 - (o0 + OB)) * OB;  // this row range's part of the G / W scratch (disjoint between the two streams)
-  const double* Vo = v.M + size_t(o0) * D;   // OB scaled reflector rows
-  double* Mb = v.M + size_t(r0) * D;
-  double* Tb = v.R + size_t(r0) * D + o0;
-  Gemm g1{Mb, Vo, Tb, v.lgG + loc, sDD, sDD, sDD, sG, D, D, D, OB, rows, OB, D, 1.0, 1.0, v.act, nullptr};
-  gemm(s, B, true, g1);
-  Gemm g2{v.lgG + loc, Tfo, nullptr, v.lgW + loc, sG, sT, 0, sG, OB, OB, 0, OB, rows, OB, OB, 1.0, 0.0, v.act, nullptr};
-  gemm(s, B, false, g2);
-  Gemm g3{v.lgG + loc, Tfo, Tb, Tb, sG, sT, sDD, sDD, OB, OB, D, D, rows, OB, OB, -1.0, 1.0, v.act, nullptr};
-  gemm(s, B, false, g3);
-  Gemm g4{v.lgW + loc, Vo, Mb, Mb, sG, sDD, sDD, sDD, OB, D, D, D, rows, D, OB, -1.0, 1.0, v.act, nullptr};
-  gemm(s, B, false, g4);
-}
-
 static void blocked_lq(const DenseView& v, int rows_total, hipStream_t s) {
   const int B = v.B, D = v.D;
   const long sDD = long(v.mr_rows) * D * D;
   const long sG = long(rows_total) * 128;
   const int tfs = 4 * PB * PB;  // panel factors of one outer block (at most four panels)
-  LargeSide* side = (v.side && !v.lq_sequential && rows_total >= 384) ? v.side : nullptr;
-  // scratch of the products inside an outer block: the last 128 rows of the G / W buffers, which no outer update reaches (its rows are
-  // counted from the end of the outer block, at least 128 rows into the stack) -- the look-ahead runs the two side by side
-  double* Gin = v.lgG + long(rows_total - 128) * 128;
-  double* Win = v.lgW + long(rows_total - 128) * 128;
-  bool pending = false;  // an update on the side stream that the main stream has not waited for yet
-  int blk = 0;
-  for (int o0 = 0; o0 < D; o0 += 128, ++blk) {
+  for (int o0 = 0; o0 < D; o0 += 128) {
     const int OB = D - o0 < 128 ? D - o0 : 128, nb = OB / PB;  // (the last outer block may be shorter: D % 128 in {0, 64})
     for (int pi = 0; pi < nb; ++pi) {
       const int p0 = o0 + pi * PB;
@@ -1070,7 +1039,7 @@ static void blocked_lq(const DenseView& v, int rows_total, hipStream_t s) {
       double* Mb = v.M + size_t(j0) * D;       // trailing rows of Mt (inside the outer block)
       double* Vp = v.M + size_t(p0) * D;       // scaled reflector rows (32 x D)
       double* Tb = v.R + size_t(j0) * D + p0;  // trailing rows of T, panel columns
-      Gemm g1{Mb, Vp, Tb, Gin, sDD, sDD, sDD, sG, D, D, D, PB, rows, PB, D, 1.0, 1.0, v.act, nullptr};
+      Gemm g1{Mb, Vp, Tb, v.lgG, sDD, sDD, sDD, sG, D, D, D, PB, rows, PB, D, 1.0, 1.0, v.act, nullptr};
       // one workgroup per trajectory would walk all of K alone (latency-bound, a quarter of the CUs busy): K-slices of 256
       // A slice must be a whole number of PD * KS = 64-wide k-steps (D = 576, 704, 832, 896 ... would otherwise
       // accumulate a clamped tail tile more than once or drop columns): among 2, 3, 4 slices take the one whose
@@ -1087,40 +1056,33 @@ static void blocked_lq(const DenseView& v, int rows_total, hipStream_t s) {
       g1.sPart = long(rows) * PB;
       gemm(s, B, true, g1);  // G = T[:, panel] + Mt V^T
       if (g1.ksplit > 1)
-        hipLaunchKernelGGL(sum_partials_kernel, dim3((rows * PB + 255) / 256, B), dim3(256), 0, s, Gin, sG, g1.sPart, rows * PB,
+        hipLaunchKernelGGL(sum_partials_kernel, dim3((rows * PB + 255) / 256, B), dim3(256), 0, s, v.lgG, sG, g1.sPart, rows * PB,
                            g1.ksplit, v.act);
-      Gemm g2{Gin, Tf, nullptr, Win, sG, long(tfs), 0, sG, PB, PB, 0, PB, rows, PB, PB, 1.0, 0.0, v.act, nullptr};
+      Gemm g2{v.lgG, Tf, nullptr, v.lgW, sG, long(tfs), 0, sG, PB, PB, 0, PB, rows, PB, PB, 1.0, 0.0, v.act, nullptr};
       gemm(s, B, false, g2);  // W = G Tf
-      Gemm g3{Gin, Tf, Tb, Tb, sG, long(tfs), sDD, sDD, PB, PB, D, D, rows, PB, PB, -1.0, 1.0, v.act, nullptr};
+      Gemm g3{v.lgG, Tf, Tb, Tb, sG, long(tfs), sDD, sDD, PB, PB, D, D, rows, PB, PB, -1.0, 1.0, v.act, nullptr};
       gemm(s, B, false, g3);  // T[:, panel] -= G Tf
-      Gemm g4{Win, Vp, Mb, Mb, sG, sDD, sDD, sDD, PB, D, D, D, rows, D, PB, -1.0, 1.0, v.act, nullptr};
+      Gemm g4{v.lgW, Vp, Mb, Mb, sG, sDD, sDD, sDD, PB, D, D, D, rows, D, PB, -1.0, 1.0, v.act, nullptr};
       gemm(s, B, false, g4);  // Mt -= W V
     }
     const int j0 = o0 + OB, rows = rows_total - j0;
     if (rows <= 0) continue;
-    const double* Vo = v.M + size_t(o0) * D;  // OB scaled reflector rows
+    double* Vo = v.M + size_t(o0) * D;        // OB scaled reflector rows
+    double* Mb = v.M + size_t(j0) * D;
+    double* Tb = v.R + size_t(j0) * D + o0;
     const long sT = 128 * 128;
-    double* Tfo = v.lgTfo + (side ? size_t(blk & 1) * B * sT : 0);  // (two buffers: the side stream may still read the previous block's)
     Gemm gg{Vo, Vo, nullptr, v.lgGram, sDD, sDD, 0, sT, D, D, 0, OB, OB, OB, D, 1.0, 0.0, v.act, nullptr};
     gemm(s, B, true, gg);  // Gram = V V^T
-    hipLaunchKernelGGL(tf_outer_kernel, dim3(B), dim3(256), 0, s, v.lgTf, v.lgGram, Tfo, nb, v.act);
-    if (!side) {
-      outer_update(v, rows_total, o0, OB, j0, rows, Tfo, s);
-      continue;
-    }
-    const int near = rows < 128 ? rows : 128;  // the rows of the next outer block (its panels wait for nothing else)
-    (void)hipEventRecord(side->ready[blk & 7], s);
-    if (pending) (void)hipStreamWaitEvent(s, side->done[(blk - 1) & 7], 0);  // these rows were last written by the previous block's far update
-    pending = false;
-    outer_update(v, rows_total, o0, OB, j0, near, Tfo, s);
-    if (rows > near) {
-      (void)hipStreamWaitEvent(side->stream, side->ready[blk & 7], 0);
-      outer_update(v, rows_total, o0, OB, j0 + near, rows - near, Tfo, side->stream);
-      (void)hipEventRecord(side->done[blk & 7], side->stream);
-      pending = true;
-    }
+    hipLaunchKernelGGL(tf_outer_kernel, dim3(B), dim3(256), 0, s, v.lgTf, v.lgGram, v.lgTfo, nb, v.act);
+    Gemm g1{Mb, Vo, Tb, v.lgG, sDD, sDD, sDD, sG, D, D, D, OB, rows, OB, D, 1.0, 1.0, v.act, nullptr};
+    gemm(s, B, true, g1);
+    Gemm g2{v.lgG, v.lgTfo, nullptr, v.lgW, sG, sT, 0, sG, OB, OB, 0, OB, rows, OB, OB, 1.0, 0.0, v.act, nullptr};
+    gemm(s, B, false, g2);
+    Gemm g3{v.lgG, v.lgTfo, Tb, Tb, sG, sT, sDD, sDD, OB, OB, D, D, rows, OB, OB, -1.0, 1.0, v.act, nullptr};
+    gemm(s, B, false, g3);
+    Gemm g4{v.lgW, Vo, Mb, Mb, sG, sDD, sDD, sDD, OB, D, D, D, rows, D, OB, -1.0, 1.0, v.act, nullptr};
+    gemm(s, B, false, g4);
   }
-  if (pending) (void)hipStreamWaitEvent(s, side->done[(blk - 1) & 7], 0);
 }
 
 }  // namespace lg

@@ -34,12 +34,6 @@ struct IsoView {
 };
 
 void iso_launch_step(const IsoView& v, const StepArg* args, const IwpConst* K, hipStream_t s);
-// Host-side companions of a dense handle on the large-D path: the stream and the events of the blocked LQ's look-ahead (pnode_dense_large.hip).
-struct LargeSide {
-  hipStream_t stream;
-  hipEvent_t ready[8], done[8];
-};
-
 struct DenseView;
 bool dense_d1_fixed_grid_supported(const DenseView& v);
 void dense_d1_launch_fixed_grid(const DenseView& v, const StepArg* args, const IwpConst* K, double* out, int G, hipStream_t s);
@@ -101,9 +95,7 @@ struct DenseView {
   double* lgW;      // [B][mr_rows*D][128]
   double* lgTf;     // [B][4][32][32]  panel factors of the current outer block
   double* lgGram;   // [B][128][128]
-  double* lgTfo;    // [2][B][128][128]   aggregated factor of the outer block (two buffers: look-ahead of the blocked LQ)
-  struct LargeSide* side;  // host-side object (second stream + events) of the look-ahead; nullptr: every launch on the handle's stream
-  int lq_sequential;       // 1: no look-ahead (pnode_set_generic_path(h, 5): A/B partner; identical bits)
+  double* lgTfo;    // [B][128][128]   aggregated factor of the outer block
   long* lgOff;      // [B]
   int user_generic;      // pnode_set_generic_path(h, 1): the caller asked for the generic kernels
   int32_t* lgMaskMerge;  // [B] fixed-point: trajectories whose running transition is merged in this operation

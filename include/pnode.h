@@ -226,8 +226,6 @@ int pnode_last_step_ms(pnode_batch* h, float* ms_out);
  * 3 = MFMA kernels with the two-launch LQ (32-row passes, csrc/pnode_dense_mfma.hip) instead of the one-launch LQ with
  * overlapping 64-row passes (csrc/pnode_dense_lq4.hip), which is what 0 selects for (nu+1)*d = 128, 192, 256.
  * 4 = large-D kernels with every batched GEMM on the 64 x 64 tile (the 128 x 128 double-buffered tile of r04 switched off; identical bits).
- * 5 = large-D kernels with the blocked LQ on one stream (r04's look-ahead -- the panels of the next outer block beside the update of the rows
- *     below it, on a second stream of the handle -- switched off; identical bits).
  * The choice must be made before the first step after pnode_set_initial (PNODE_ESTATE afterwards): the paths keep the state
  * factor in different layouts.
  * No environment variable influences the library: the choice is per handle, through this call only. */

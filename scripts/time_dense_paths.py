@@ -4,7 +4,7 @@
   python scripts/time_dense_paths.py N B PATH [filter|fixedpoint] [--phases] [--nu=3]
 
 PATH: 0 default dispatch, 1 generic kernels, 2 large-D kernels, 3 MFMA kernels with the two-launch LQ, 4 large-D kernels with the 64 x 64
-GEMM tile only, 5 large-D kernels without the look-ahead of the blocked LQ (pnode_set_generic_path).
+GEMM tile only (pnode_set_generic_path).
 --phases prints the begin | LQ input | LQ | measurement-update split from HIP events (filter only).
 Run under `rocprofv3 --kernel-trace --output-format csv -d OUT -- python3 scripts/time_dense_paths.py ...` and feed OUT to
 scripts/parse_kernel_trace.py for the per-kernel table.
