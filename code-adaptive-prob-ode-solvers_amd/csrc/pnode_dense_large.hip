@@ -40,6 +40,10 @@ struct Gemm {
   const long* offB;    // same for B
   int ksplit;          // > 1 (N <= 32 only): blockIdx.x selects a K-slice; slice kx writes its partial product to
   long sPart;          //   C + kx * sPart (C0 is added by slice 0 only); sum_partials_kernel adds the slices up
+  double* E;           // optional second output of the SAME product, updated in place: E[b] = E[b] + ealpha * A op(B)  (no K-slices)
+  long sE;             //   -- the block reflector's W = G Tf and T[:, blk] -= G Tf are one product, not two
+  int lde;
+  double ealpha;
 };
 
 // PD = register prefetch depth in k-tiles: the skinny shapes (N <= 32: a handful of workgroups per trajectory, K up to D)
@@ -154,6 +158,27 @@ __global__ __launch_bounds__(256) void gemm_kernel(Gemm g) {
         const int row = m0 + wm * 32 + tm * 16 + 4 * q + gq, col = n0 + wn * 32 + tn * 16 + r;
         if (row < g.M && col < g.N) C[long(row) * g.ldc + col] = fma(g.beta, c0v[tm][tn][q], g.alpha * acc[tm][tn][q]);
       }
+  if (g.E) {  // (the same expression a separate launch with C0 = C = E, beta = 1 would evaluate)
+    double* E = g.E + long(b) * g.sE;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = m0 + wm * 32 + tm * 16 + 4 * q + gq, col = n0 + wn * 32 + tn * 16 + r;
+          c0v[tm][tn][q] = (row < g.M && col < g.N) ? E[long(row) * g.lde + col] : 0.0;
+        }
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = m0 + wm * 32 + tm * 16 + 4 * q + gq, col = n0 + wn * 32 + tn * 16 + r;
+          if (row < g.M && col < g.N) E[long(row) * g.lde + col] = fma(1.0, c0v[tm][tn][q], g.ealpha * acc[tm][tn][q]);
+        }
+  }
 }
 
 // The same product for the square shapes of the blocked LQ and of the measurement update (M, N >= 128, K >= 64): 128 x 128 tile per
@@ -310,6 +335,62 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(double* __restrict__ 
   }
 }
 
+// Inside an outer block, after G = T[:, panel] + Mt V^T of a panel (rows <= 96, 32 columns, possibly in K-slices): the slices summed, W = G Tf
+// and T[:, panel] -= G Tf in ONE launch, one workgroup per 32 rows (it replaces sum_partials_kernel and two 32-wide gemm_kernel launches;
+// the sums and products in the same order, element by element: identical bits).
+__global__ __launch_bounds__(256) void panel_gw_kernel(const double* __restrict__ G, long sG, long sPart, int nparts, const double* __restrict__ Tf,
+                                                       long sTf, double* __restrict__ W, double* __restrict__ T, long sT, int ldt, int rows,
+                                                       const int32_t* __restrict__ act) {
+  __shared__ double Gs[32 * 33];
+  __shared__ double Ts[32 * 33];
+  const int b = blockIdx.y;
+  if (act && !act[b]) return;
+  const int r0 = blockIdx.x * 32, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 15, gq = lane >> 4;
+  const double* g = G + long(b) * sG;
+  const double* tf = Tf + long(b) * sTf;
+  // four elements per thread, every load of every slice in flight at once (nparts <= 4)
+  double part[4][4], tfv[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int e = tid + 256 * u, row = e >> 5, col = e & 31;
+    const long idx = long(r0 + row < rows ? r0 + row : rows - 1) * 32 + col;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) part[u][k] = g[idx + long(k < nparts ? k : 0) * sPart];
+    tfv[u] = tf[e];
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int e = tid + 256 * u, row = e >> 5, col = e & 31;
+    double acc = part[u][0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) acc = (k < nparts) ? acc + part[u][k] : acc;
+    Gs[row * 33 + col] = (r0 + row < rows) ? acc : 0.0;
+    Ts[row * 33 + col] = tfv[u];
+  }
+  __syncthreads();
+  // wavefront wv: the 16 x 16 tile (tm, tn) = (wv >> 1, wv & 1) of the 32 x 32 product
+  const int tm = wv >> 1, tn = wv & 1;
+  double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int k4 = 0; k4 < 8; ++k4) acc = LG_MFMA(Gs[(tm * 16 + r) * 33 + k4 * 4 + gq], Ts[(k4 * 4 + gq) * 33 + tn * 16 + r], acc);
+  double* w = W + long(b) * sG;
+  double* t = T + long(b) * sT;
+  double told[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = r0 + tm * 16 + 4 * q + gq, col = tn * 16 + r;
+    told[q] = t[long(row < rows ? row : rows - 1) * ldt + col];
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = r0 + tm * 16 + 4 * q + gq, col = tn * 16 + r;
+    if (row < rows) {
+      w[long(row) * 32 + col] = fma(0.0, 0.0, 1.0 * acc[q]);
+      t[long(row) * ldt + col] = fma(1.0, told[q], -1.0 * acc[q]);
+    }
+  }
+}
+
 // pnode_set_generic_path(h, 4) pins the 64 x 64 tile (A/B partner of gemm128_kernel); set by the entry points below from the handle
 static thread_local bool gemm_tile128 = true;
 static void gemm(hipStream_t s, int batch, bool transB, const Gemm& g) {
@@ -325,7 +406,7 @@ static void gemm(hipStream_t s, int batch, bool transB, const Gemm& g) {
       hipLaunchKernelGGL((gemm_kernel<true, 4, 1, 1>), grid, dim3(256), 0, s, g);
     else
       hipLaunchKernelGGL((gemm_kernel<false, 4, 1, 1>), grid, dim3(256), 0, s, g);
-  } else if (gemm_tile128 && g.ksplit <= 1 && g.M >= 128 && g.N >= 128 && g.K >= 512 &&
+  } else if (gemm_tile128 && !g.E && g.ksplit <= 1 && g.M >= 128 && g.N >= 128 && g.K >= 512 &&
              long((g.M + 127) / 128) * ((g.N + 127) / 128) * batch >= 256) {
     // Long inner dimension only (measured at D = 1024, B = 64, profiles/r04_gemm_tiles.txt): 1024 x 256 x 1024 goes from 55 to 62 TFLOP/s,
     // while the rank-128 / rank-256 updates of the blocked LQ (K <= 256, bound by the traffic of C: 16 flops per byte) lose 12 % on the
@@ -1055,13 +1136,9 @@ static void blocked_lq(const DenseView& v, int rows_total, hipStream_t s) {
       }
       g1.sPart = long(rows) * PB;
       gemm(s, B, true, g1);  // G = T[:, panel] + Mt V^T
-      if (g1.ksplit > 1)
-        hipLaunchKernelGGL(sum_partials_kernel, dim3((rows * PB + 255) / 256, B), dim3(256), 0, s, v.lgG, sG, g1.sPart, rows * PB,
-                           g1.ksplit, v.act);
-      Gemm g2{v.lgG, Tf, nullptr, v.lgW, sG, long(tfs), 0, sG, PB, PB, 0, PB, rows, PB, PB, 1.0, 0.0, v.act, nullptr};
-      gemm(s, B, false, g2);  // W = G Tf
-      Gemm g3{v.lgG, Tf, Tb, Tb, sG, long(tfs), sDD, sDD, PB, PB, D, D, rows, PB, PB, -1.0, 1.0, v.act, nullptr};
-      gemm(s, B, false, g3);  // T[:, panel] -= G Tf
+      // K-slices summed, W = G Tf, T[:, panel] -= G Tf
+      hipLaunchKernelGGL(panel_gw_kernel, dim3((rows + 31) / 32, B), dim3(256), 0, s, v.lgG, sG, g1.sPart, g1.ksplit, Tf, long(tfs), v.lgW, Tb, sDD, D,
+                         rows, v.act);
       Gemm g4{v.lgW, Vp, Mb, Mb, sG, sDD, sDD, sDD, PB, D, D, D, rows, D, PB, -1.0, 1.0, v.act, nullptr};
       gemm(s, B, false, g4);  // Mt -= W V
     }
@@ -1077,9 +1154,8 @@ static void blocked_lq(const DenseView& v, int rows_total, hipStream_t s) {
     Gemm g1{Mb, Vo, Tb, v.lgG, sDD, sDD, sDD, sG, D, D, D, OB, rows, OB, D, 1.0, 1.0, v.act, nullptr};
     gemm(s, B, true, g1);
     Gemm g2{v.lgG, v.lgTfo, nullptr, v.lgW, sG, sT, 0, sG, OB, OB, 0, OB, rows, OB, OB, 1.0, 0.0, v.act, nullptr};
+    g2.E = Tb; g2.sE = sDD; g2.lde = D; g2.ealpha = -1.0;  // W = G Tf and T[:, blk] -= G Tf: one product, two outputs
     gemm(s, B, false, g2);
-    Gemm g3{v.lgG, v.lgTfo, Tb, Tb, sG, sT, sDD, sDD, OB, OB, D, D, rows, OB, OB, -1.0, 1.0, v.act, nullptr};
-    gemm(s, B, false, g3);
     Gemm g4{v.lgW, Vo, Mb, Mb, sG, sDD, sDD, sDD, OB, D, D, D, rows, D, OB, -1.0, 1.0, v.act, nullptr};
     gemm(s, B, false, g4);
   }
