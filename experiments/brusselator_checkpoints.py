@@ -91,6 +91,7 @@ def main(argv=None):
         print(f"{N:5d} {steps:9d} {int(golden['num_steps_checkpoint'][i]):9d} {count1:10.3f} {golden['runtime_checkpoint'][i]:13.3f} {dev}",
               flush=True)
     if not args.nosave:
+        os.makedirs(args.outdir, exist_ok=True)
         np.save(os.path.join(args.outdir, "data_checkpoint.npy"), results, allow_pickle=True)
         np.save(os.path.join(args.outdir, "data_textbook.npy"), textbook, allow_pickle=True)
 

@@ -65,6 +65,7 @@ def main(argv=None):
     for name, (rt, sol) in runs.items():
         print(f"  {name:17s} {len(sol.t):9,d} points  {rt:8.4f} s")
     if not args.nosave:
+        os.makedirs(args.outdir, exist_ok=True)
         pre = os.path.join(args.outdir, "vdp")
         np.save(pre + "_baseline_grid.npy", base.t)
         np.save(pre + "_baseline_solution.npy", base.u)

@@ -117,6 +117,7 @@ def main(argv=None):
             print(f"K={n:4d} tol={tol:.0e}: steps {nsteps:6,d} (reference {want[tol]:6,d})  AS {t_as:.3f} s  ATS {t_ats:.3f} s")
             i += 1
     if not args.nosave:
+        os.makedirs(args.outdir, exist_ok=True)
         np.save(os.path.join(args.outdir, "data_results_vs_interpolation.npy"), results, allow_pickle=True)
         np.save(os.path.join(args.outdir, "data_solution_vs_interpolation.npy"), baseline.u)
         print("saved to", args.outdir)
