@@ -391,9 +391,9 @@ __global__ __launch_bounds__(256) void panel_gw_kernel(const double* __restrict_
   }
 }
 
-// pnode_set_generic_path(h, 4) pins the 64 x 64 tile (A/B partner of gemm128_kernel); set by the entry points below from the handle
-static thread_local bool gemm_tile128 = true;
-static void gemm(hipStream_t s, int batch, bool transB, const Gemm& g) {
+// (v.gemm_tile64: pnode_set_generic_path(h, 4) pins the 64 x 64 tile, the A/B partner of gemm128_kernel)
+static void gemm(const DenseView& v, hipStream_t s, int batch, bool transB, const Gemm& g) {
+  const bool gemm_tile128 = !v.gemm_tile64;
   if (g.M <= 0 || g.N <= 0 || batch <= 0) return;
 #ifdef PNODE_TIMING_BUILD
   fprintf(stderr, "gemm M %d N %d K %d batch %d transB %d ksplit %d beta %g\n", g.M, g.N, g.K, batch, int(transB), g.ksplit, g.beta);
@@ -945,7 +945,7 @@ static void potrf(hipStream_t s, const DenseView& v) {
       double* sub = v.S + size_t(j0 + PB) * d + j0;  // rows below, panel columns
       Gemm g{sub, sub, v.S + size_t(j0 + PB) * d + j0 + PB, v.S + size_t(j0 + PB) * d + j0 + PB,
              long(d) * d, long(d) * d, long(d) * d, long(d) * d, d, d, d, d, rem, rem, PB, -1.0, 1.0, v.act, nullptr};
-      gemm(s, v.B, true, g);
+      gemm(v, s, v.B, true, g);
     }
   }
 }
@@ -1135,12 +1135,12 @@ static void blocked_lq(const DenseView& v, int rows_total, hipStream_t s) {
           }
       }
       g1.sPart = long(rows) * PB;
-      gemm(s, B, true, g1);  // G = T[:, panel] + Mt V^T
+      gemm(v, s, B, true, g1);  // G = T[:, panel] + Mt V^T
       // K-slices summed, W = G Tf, T[:, panel] -= G Tf
       hipLaunchKernelGGL(panel_gw_kernel, dim3((rows + 31) / 32, B), dim3(256), 0, s, v.lgG, sG, g1.sPart, g1.ksplit, Tf, long(tfs), v.lgW, Tb, sDD, D,
                          rows, v.act);
       Gemm g4{v.lgW, Vp, Mb, Mb, sG, sDD, sDD, sDD, PB, D, D, D, rows, D, PB, -1.0, 1.0, v.act, nullptr};
-      gemm(s, B, false, g4);  // Mt -= W V
+      gemm(v, s, B, false, g4);  // Mt -= W V
     }
     const int j0 = o0 + OB, rows = rows_total - j0;
     if (rows <= 0) continue;
@@ -1149,29 +1149,27 @@ static void blocked_lq(const DenseView& v, int rows_total, hipStream_t s) {
     double* Tb = v.R + size_t(j0) * D + o0;
     const long sT = 128 * 128;
     Gemm gg{Vo, Vo, nullptr, v.lgGram, sDD, sDD, 0, sT, D, D, 0, OB, OB, OB, D, 1.0, 0.0, v.act, nullptr};
-    gemm(s, B, true, gg);  // Gram = V V^T
+    gemm(v, s, B, true, gg);  // Gram = V V^T
     hipLaunchKernelGGL(tf_outer_kernel, dim3(B), dim3(256), 0, s, v.lgTf, v.lgGram, v.lgTfo, nb, v.act);
     Gemm g1{Mb, Vo, Tb, v.lgG, sDD, sDD, sDD, sG, D, D, D, OB, rows, OB, D, 1.0, 1.0, v.act, nullptr};
-    gemm(s, B, true, g1);
+    gemm(v, s, B, true, g1);
     Gemm g2{v.lgG, v.lgTfo, nullptr, v.lgW, sG, sT, 0, sG, OB, OB, 0, OB, rows, OB, OB, 1.0, 0.0, v.act, nullptr};
     g2.E = Tb; g2.sE = sDD; g2.lde = D; g2.ealpha = -1.0;  // W = G Tf and T[:, blk] -= G Tf: one product, two outputs
-    gemm(s, B, false, g2);
+    gemm(v, s, B, false, g2);
     Gemm g4{v.lgW, Vo, Mb, Mb, sG, sDD, sDD, sDD, OB, D, D, D, rows, D, OB, -1.0, 1.0, v.act, nullptr};
-    gemm(s, B, false, g4);
+    gemm(v, s, B, false, g4);
   }
 }
 
 }  // namespace lg
 
 void dense_large_lq(const DenseView& v, int rows_total, hipStream_t s) {
-  lg::gemm_tile128 = !v.gemm_tile64;
   lg::blocked_lq(v, rows_total, s);
 }
 
 // After the 2D-row LQ of a predict: G_p = C21_p (L^-_p)^-1 (blocked right triangular solve), plain coordinates,
 // xi, merge with the running transition, and the LQ of the merged noise stack [Lam0 | G0 Lam] (rows 0..D-1 of R / M).
 void dense_large_fp_backward(const DenseView& v, const FpArg* fa, const IwpConst* K, hipStream_t s) {
-  lg::gemm_tile128 = !v.gemm_tile64;
   using namespace lg;
   const int B = v.B, D = v.D;
   const long DD = long(D) * D, sDD = 2 * DD;
@@ -1182,16 +1180,16 @@ void dense_large_fp_backward(const DenseView& v, const FpArg* fa, const IwpConst
     if (jb > 0) {
       Gemm g{C21 + jb * PB, v.R + size_t(jb) * PB * D, C21, C21, sDD, sDD, sDD, sDD, D, D, D, D, D, jb * PB, PB, -1.0, 1.0, v.act,
              nullptr};
-      gemm(s, B, false, g);  // C21[:, 0:jb*32] -= X[:, jb] Lm[jb, 0:jb*32]
+      gemm(v, s, B, false, g);  // C21[:, 0:jb*32] -= X[:, jb] Lm[jb, 0:jb*32]
     }
   }
   hipLaunchKernelGGL(fp_scale_kernel, dim3(64, B), dim3(256), 0, s, v, fa, K);
   hipLaunchKernelGGL(fp_xi_kernel, dim3(32, B), dim3(256), 0, s, v, fa);
   {
     Gemm gd{v.cG, C21, nullptr, v.cG, 0, sDD, 0, 0, D, D, 0, D, D, D, D, 1.0, 0.0, v.lgMaskMerge, v.lgOffD, v.lgOffS, nullptr};
-    gemm(s, B, false, gd);  // G_dst = G0 G
+    gemm(v, s, B, false, gd);  // G_dst = G0 G
     Gemm gl{v.cG, v.M + DD, nullptr, v.M, 0, sDD, 0, sDD, D, D, 0, D, D, D, D, 1.0, 0.0, v.lgMaskMerge, nullptr, v.lgOffS, nullptr};
-    gemm(s, B, false, gl);  // Mt := G0 Lam
+    gemm(v, s, B, false, gl);  // Mt := G0 Lam
   }
   hipLaunchKernelGGL(fp_merge_misc_kernel, dim3(64, B), dim3(256), 0, s, v, fa);
   blocked_lq(v, D, s);
@@ -1212,7 +1210,6 @@ bool dense_use_large(const DenseView& v) {
 }
 
 void dense_large_launch_step(const DenseView& v, const StepArg* args, const IwpConst* K, hipStream_t s, const PhaseEvents* ev) {
-  lg::gemm_tile128 = !v.gemm_tile64;
   using namespace lg;
   auto mark = [&](int i) {
     if (ev) (void)hipEventRecord(ev->ev[i], s);
@@ -1224,7 +1221,7 @@ void dense_large_launch_step(const DenseView& v, const StepArg* args, const IwpC
   hipLaunchKernelGGL(begin_a_kernel, dim3(d >= 128 ? 8 : 2, B), dim3(256), shm_a, s, v, args, K);
   {
     Gemm g{v.X, v.X, nullptr, v.S, long(d) * D, long(d) * D, 0, long(d) * d, D, D, 0, d, d, d, (k + 1) * d, 1.0, 0.0, v.act, nullptr};
-    gemm(s, B, true, g);
+    gemm(v, s, B, true, g);
   }
   potrf(s, v);
   hipLaunchKernelGGL(begin_c_kernel, dim3(B), dim3(256), 0, s, v, args, v.lgW);
@@ -1238,11 +1235,11 @@ void dense_large_launch_step(const DenseView& v, const StepArg* args, const IwpC
   hipLaunchKernelGGL(scale_t_kernel, dim3(64, B), dim3(256), 0, s, v, args, K);
   {  // F = L^-[k-block rows] - J L^-[0:kd rows]      (d x D)
     Gemm f{v.J, v.M, v.M + size_t(kd) * D, v.X, long(d) * kd, sDD, sDD, long(d) * D, kd, D, D, D, d, D, kd, -1.0, 1.0, v.act, nullptr};
-    gemm(s, B, false, f);
+    gemm(v, s, B, false, f);
   }
   {
     Gemm g{v.X, v.X, nullptr, v.S, long(d) * D, long(d) * D, 0, long(d) * d, D, D, 0, d, d, d, D, 1.0, 0.0, v.act, nullptr};
-    gemm(s, B, true, g);  // S = F F^T
+    gemm(v, s, B, true, g);  // S = F F^T
   }
   potrf(s, v);
   hipLaunchKernelGGL(solve_wz_kernel, dim3(B), dim3(256), 0, s, v, args);
@@ -1253,15 +1250,15 @@ void dense_large_launch_step(const DenseView& v, const StepArg* args, const IwpC
       Gemm g{v.S + size_t(ib + 1) * PB * d + ib * PB, v.X + size_t(ib) * PB * D, v.X + size_t(ib + 1) * PB * D,
              v.X + size_t(ib + 1) * PB * D, long(d) * d, long(d) * D, long(d) * D, long(d) * D, d, D, D, D, rem, D, PB, -1.0, 1.0,
              v.act, nullptr};
-      gemm(s, B, false, g);
+      gemm(v, s, B, false, g);
     }
   }
   {
     Gemm y{v.M, v.X, nullptr, v.Ft, sDD, long(d) * D, 0, long(D) * d, D, D, 0, d, D, d, D, 1.0, 0.0, v.act, nullptr};
-    gemm(s, B, true, y);  // Y = L^- W^T   (D x d)
+    gemm(v, s, B, true, y);  // Y = L^- W^T   (D x d)
     // L = L^- - Y W, written to each trajectory's destination slot (per-trajectory offsets)
     Gemm u{v.Ft, v.X, v.M, v.U, long(D) * d, long(d) * D, sDD, 0, d, D, D, D, D, D, d, -1.0, 1.0, v.act, v.lgOff};
-    gemm(s, B, false, u);
+    gemm(v, s, B, false, u);
   }
   hipLaunchKernelGGL(finish_mean_kernel, dim3(32, B), dim3(256), 0, s, v, args);
   hipLaunchKernelGGL(finish_kernel, dim3(B), dim3(256), 0, s, v, args);
