@@ -224,3 +224,36 @@ def test_stored_backward_transitions_vs_oracle(hip_lib, nu):
         assert relmax(xi[0, c], oc.xi) < eps, c
         assert np.all(np.diag(Lam[0, c]) >= 0.0) and np.all(np.tril(Lam[0, c], -1) == 0.0)
         assert relmax(Lam[0, c].T @ Lam[0, c], oc.Lam @ oc.Lam.T) < 10 * eps, c
+
+
+def test_large_path_gemm_tiles_give_identical_bits(hip_lib):
+    """pnode_set_generic_path(h, 2 | 4): the large-D kernels with the 128 x 128 double-buffered GEMM tile where the shape allows
+    (long inner dimension, at least 256 tiles in the launch) against the 64 x 64 tile everywhere -- the same sums in the same order,
+    element by element: error estimates, means and factors are equal bit for bit after several attempts (D = 512, 128
+    trajectories: the products with K = 512 take the large tile). Same kernels as BASELINE config 5's, at a size the suite can afford."""
+    from probdiffeq_hip import _backend
+
+    N, nu, B = 64, 3, 128
+    vf = V.brusselator(N)
+    y0 = np.stack([brusselator_y0(N, 0.05 * b) for b in range(B)])
+    tc = np.stack(tcoeffs(vf, [y0], nu), axis=1)
+    out = []
+    for path in (2, 4):
+        bt = _backend.Batch(batch=B, d=vf.d, nu=nu, ode_order=1, model="dense", correction="ts1", strategy="filter", calibration="dynamic",
+                            vf_id=vf.vf_id, vf_params=vf.param_array(), num_checkpoints=2)
+        try:
+            bt.set_generic_path(path)
+            bt.set_initial(tc, np.zeros(B), np.ones(B))
+            bt.set_tolerances(1e-6, 1e-6)
+            err, one = np.zeros(B), np.ones(B, np.uint8)
+            errs = []
+            for dt in (0.004, 0.006, 0.005):
+                bt.attempt_step(np.full(B, dt) * (1.0 + 0.001 * np.arange(B)), one, err)
+                bt.commit(one)
+                errs.append(err.copy())
+            out.append((np.stack(errs), bt.read_mean(0), bt.read_factor(0)))
+        finally:
+            bt.close()
+    (e2, m2, f2), (e4, m4, f4) = out
+    assert np.all(np.isfinite(e2)) and np.all(np.isfinite(f2)) and np.max(np.abs(f2)) > 0
+    assert np.array_equal(e2, e4) and np.array_equal(m2, m4) and np.array_equal(f2, f4)
