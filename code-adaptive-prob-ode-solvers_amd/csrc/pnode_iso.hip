@@ -294,6 +294,12 @@ __device__ __forceinline__ double iso_attempt(const IsoView& v, const IwpConst& 
     }
   }
 
+  // Lanes beyond d repeat the work of dimension d - 1 on clamped indices (no lane is ever disabled). That is harmless only while the
+  // repeating lanes run in lockstep with the lane that owns d - 1, i.e. inside ONE wavefront: a wavefront of a team (W = 4) whose 64
+  // dimensions all lie beyond d would repeat another wavefront's read-modify-write of m[d - 1] at a different time (found by
+  // scripts/soak_iso_shapes.py at d = 130 .. 140: the smoother's offsets and the corrected mean of the last dimension were updated twice).
+  // Such a wavefront skips the loop bodies -- a wave-uniform branch -- and still takes part in the barriers and sums.
+  const int wbase = __builtin_amdgcn_readfirstlane(lane & ~(kWave - 1));
   const double dt = arg.dt;
   double p[N], pinv[N], pl, pil;
   preconditioner_lanes<N>(dt, P.fact, l, p, pinv, pl, pil);
@@ -304,6 +310,7 @@ __device__ __forceinline__ double iso_attempt(const IsoView& v, const IwpConst& 
 
   // --- pass A: mean extrapolation  m^- = P Abar P^{-1} m
   for (int j0 = 0; j0 < d; j0 += kTeam) {
+    if (W > 1 && j0 + wbase >= d) continue;  // (see wbase)
     const int j = j0 + lane;
     const bool on = j < d;
     const int jc = on ? j : d - 1;
@@ -334,6 +341,7 @@ __device__ __forceinline__ double iso_attempt(const IsoView& v, const IwpConst& 
   const double tnew = arg.t + dt;
   double zz = 0.0;
   for (int j0 = 0; j0 < d; j0 += kTeam) {
+    if (W > 1 && j0 + wbase >= d) continue;  // (see wbase)
     const int j = j0 + lane;
     const bool on = j < d;
     const int jc = on ? j : d - 1;
@@ -366,6 +374,7 @@ __device__ __forceinline__ double iso_attempt(const IsoView& v, const IwpConst& 
     const double* xi0 = v.cxi + (size_t(arg.src) * sB + b) * N * d;
     double* xid = v.cxi + (size_t(arg.dst) * sB + b) * N * d;
     for (int j0 = 0; j0 < d; j0 += kTeam) {
+      if (W > 1 && j0 + wbase >= d) continue;  // (see wbase)
       const int j = j0 + lane;
       const bool on = j < d;
       const int jc = on ? j : d - 1;
@@ -401,6 +410,7 @@ __device__ __forceinline__ double iso_attempt(const IsoView& v, const IwpConst& 
   const double atol = v.atol[b], rtol = v.rtol[b];
   double acc2 = 0.0;
   for (int j0 = 0; j0 < d; j0 += kTeam) {
+    if (W > 1 && j0 + wbase >= d) continue;  // (see wbase)
     const int j = j0 + lane;
     const bool on = j < d;
     const int jc = on ? j : d - 1;

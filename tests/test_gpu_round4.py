@@ -257,3 +257,33 @@ def test_large_path_gemm_tiles_give_identical_bits(hip_lib):
     (e2, m2, f2), (e4, m4, f4) = out
     assert np.all(np.isfinite(e2)) and np.all(np.isfinite(f2)) and np.max(np.abs(f2)) > 0
     assert np.array_equal(e2, e4) and np.array_equal(m2, m4) and np.array_equal(f2, f4)
+
+
+@pytest.mark.parametrize("strategy", ["filter", "fixedpoint"])
+@pytest.mark.parametrize("N", [65, 70, 96, 100])
+def test_four_wavefront_kernels_when_the_dimensions_do_not_fill_the_team(hip_lib, N, strategy):
+    """d = 130, 140, 192, 200 ODE dimensions on the kernels that give a trajectory four wavefronts (d > 128): the last wavefronts have few
+    or no dimensions of their own. Lanes beyond d repeat dimension d - 1 -- harmless inside one wavefront, a race across wavefronts (a whole
+    wavefront of repeats redid another wavefront's update of m[d - 1] and of the smoother's offset at its own time: NaNs with the host
+    controller at d = 140, found by scripts/soak_iso_shapes.py; such a wavefront now skips the loop bodies). Host and device controller
+    against the oracle: identical decisions, smoothed means to 1e-8."""
+    vf = V.brusselator(N)
+    impl.select("isotropic", ode_shape=(vf.d,))
+    nu, tol = 2, 1e-3
+    solver = _solver(nu, strategy)
+    y0 = np.stack([brusselator_y0(N, 0.3), brusselator_y0(N, 0.7)])
+    tcs = taylor.odejet_padded_scan(vf, [y0], num=nu)
+    init = solver.initial_condition(tcs, 1.0)
+    save_at = np.linspace(0.0, 0.12, 4)
+    asolver = ivpsolve.adaptive(solver, atol=1e-3 * tol, rtol=tol)
+    cfg = po.SolverConfig(nu=nu, model="isotropic", correction="ts0", strategy=strategy, calibration="dynamic")
+    refs = []
+    for b in range(2):
+        osol = po.solve_adaptive_save_at(cfg, po.AdaptiveConfig(1e-3 * tol, tol), oracle_problem(vf), po.initial_state(cfg, [c[b] for c in tcs], 0.0),
+                                         save_at, 0.01)
+        refs.append((osol.num_steps, po.markov_marginals_reverse(cfg, osol)[:, 0] if strategy == "fixedpoint" else osol.u))
+    for dc in (False, True):
+        sol = ivpsolve.solve_adaptive_save_at(vf, init, save_at=save_at, dt0=0.01, adaptive_solver=asolver, device_controller=dc)
+        for b in range(2):
+            assert np.array_equal(sol.num_steps[b], refs[b][0]) and refs[b][0][-1] > 20, (dc, b, sol.num_steps[b], refs[b][0])
+            assert relmax(sol.u[b], refs[b][1]) < 1e-8, (dc, b)
