@@ -20,9 +20,11 @@ from probdiffeq_hip import vector_fields as V  # noqa: E402
 from probdiffeq_hip.impl import impl  # noqa: E402
 
 
-def main():
-    rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
-    count = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+def main(seed=None, count=None):
+    """Returns (configurations whose decisions differ or whose outputs are non-finite, configurations with identical decisions and outputs apart by > 1e-9)."""
+    seed = int(sys.argv[1]) if seed is None and len(sys.argv) > 1 else (seed or 0)
+    count = int(sys.argv[2]) if count is None and len(sys.argv) > 2 else (count or 60)
+    rng = np.random.default_rng(seed)
     bad = drift = 0
     t0 = time.time()
     fixed = [(24, 3, "fixedpoint"), (32, 8, "fixedpoint"), (33, 5, "filter"), (70, 4, "fixedpoint"), (1, 8, "fixedpoint"), (8, 1, "filter")]
@@ -59,8 +61,9 @@ def main():
             status.append(f"{dc}:{'ok' if ok else ('MISMATCH' if not same else 'DRIFT')}({rel:.1e})")
         print(f"d={vf.d:3d} nu={nu} {strategy:10s} steps={host.num_steps[:, -1].tolist()} " + " ".join(status), flush=True)
     print(f"{count} configurations, {bad} mismatches ({drift} of them with identical decisions and outputs apart by more than 1e-9), {time.time() - t0:.0f} s")
-    sys.exit(1 if bad else 0)
+    return bad - drift, drift
 
 
 if __name__ == "__main__":
-    main()
+    hard, soft = main()
+    sys.exit(1 if hard + soft else 0)

@@ -287,3 +287,19 @@ def test_four_wavefront_kernels_when_the_dimensions_do_not_fill_the_team(hip_lib
         for b in range(2):
             assert np.array_equal(sol.num_steps[b], refs[b][0]) and refs[b][0][-1] > 20, (dc, b, sol.num_steps[b], refs[b][0])
             assert relmax(sol.u[b], refs[b][1]) < 1e-8, (dc, b)
+
+
+def test_shape_soak_of_the_isotropic_kernels(hip_lib):
+    """scripts/soak_iso_shapes.py at a fixed seed, 36 configurations (random d = 2 .. 140, nu = 1 .. 8, filter / fixed-point smoother, three tolerances): every
+    device-resident controller takes the host controller's decisions exactly and ends finite. (Outputs apart by more than 1e-9 with identical decisions are
+    counted separately -- nu >= 6 and the stiff large-N Brusselator amplify rounding differences between two kernels, profiles/r04_iso_shape_soak.txt -- and
+    must stay rare.)"""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("soak_iso_shapes", os.path.join(root, "scripts", "soak_iso_shapes.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    hard, soft = mod.main(seed=3, count=36)
+    assert hard == 0 and soft <= 3, (hard, soft)
