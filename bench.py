@@ -527,6 +527,8 @@ def main():
                 hbm["measured_GBps"] = meas_bytes / (step_ms * 1e-3) / 1e9
                 hbm["measured_frac"] = hbm["measured_GBps"] / HBM_PEAK_GBS
             out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "hbm": hbm,
+                               "peak_sustained_by_probe": {"value": 77.8, "unit": "TFLOP/s", "source": "scripts/mfma_probe.hip, profiles/r04_mfma_probe.txt: "
+                                                           "v_mfma_f64_16x16x4_f64 with operands in registers, 1.7 s run, not re-measured in this run"},
                                "frac": achieved / FP64_PEAK_TFLOPS, "traffic": measured_traffic("dense_lq4_mfma_kernel" if one_launch_lq else "dense_lq2_mfma_kernel", B),
                                "traffic_source": "profiles/" + next((n for n in PMC_SUMMARIES if os.path.exists(os.path.join(ROOT, "profiles", n))), "-")
                                                  + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command, separate passes; not re-measured in this run)",
