@@ -596,58 +596,63 @@ __global__ __launch_bounds__(1024) void lq_panel_kernel(DenseView v, int p0, dou
 // Compact-WY factor of an outer block of nb 32-row panels from the panel factors (diagonal blocks) and the Gram matrix
 // of the scaled reflector rows: Tf^-1 = diag-blocks(Tf_p^-1) + striu-blocks(V V^T), inverted by block back-substitution
 //      X_ii = Tf_i ,   X_ij = -Tf_i sum_{l=i+1..j} Gram_il X_lj   (j > i).
+// r04: everything the back-substitution touches stays in LDS (the upper blocks of X and of the Gram matrix: 17 blocks of 32 x 33 doubles,
+// 144 KB of dynamic LDS) -- one pass over global memory in, one out, instead of a global round trip per 32 x 32 product -- and the
+// products run on the matrix cores (one 16 x 16 output tile per wavefront; the scalar version read two LDS operands per multiply-add).
+constexpr int kTfBlock = PB * (PB + 1);
+constexpr size_t kTfOuterShm = 17 * size_t(kTfBlock) * sizeof(double);
 __global__ __launch_bounds__(256) void tf_outer_kernel(const double* __restrict__ Tfp, const double* __restrict__ Gram,
                                                        double* __restrict__ Tfo, int nb, const int32_t* __restrict__ act) {
   constexpr int LS = PB + 1;
-  __shared__ double Gs[PB * LS], Xs[PB * LS], Ts[PB * LS], tmp[PB * LS];
+  extern __shared__ double tf_sm[];
+  double* Xb = tf_sm;                  // block (i, j), i <= j, at index j (j + 1) / 2 + i
+  double* Gb = tf_sm + 10 * kTfBlock;  // block (i, l), i < l, at index l (l - 1) / 2 + i
+  double* tmp = tf_sm + 16 * kTfBlock;
   const int b = blockIdx.x;
   if (act && !act[b]) return;
-  const int OBs = nb * PB, tid = threadIdx.x;
+  const int OBs = nb * PB, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 15, gq = lane >> 4;
+  const int tm = wv >> 1, tn = wv & 1;  // this wavefront's 16 x 16 tile of every 32 x 32 product
   const double* tp = Tfp + size_t(b) * 4 * PB * PB;  // fixed per-trajectory strides (at most four panels per outer block)
   const double* G = Gram + size_t(b) * 128 * 128;
   double* X = Tfo + size_t(b) * 128 * 128;
-  for (int e = tid; e < OBs * OBs; e += 256) {
-    const int r = e / OBs, c = e % OBs;
-    X[e] = (r / PB == c / PB) ? tp[(r / PB) * PB * PB + (r % PB) * PB + (c % PB)] : 0.0;
-  }
+  auto xb = [&](int i, int j) { return Xb + (j * (j + 1) / 2 + i) * kTfBlock; };
+  auto gb = [&](int i, int l) { return Gb + (l * (l - 1) / 2 + i) * kTfBlock; };
+  for (int i = 0; i < nb; ++i)
+    for (int j = i; j < nb; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int e = tid + 256 * q, rr = e >> 5, cc = e & 31;
+        if (j == i) xb(i, i)[rr * LS + cc] = tp[i * PB * PB + e];
+        else gb(i, j)[rr * LS + cc] = G[size_t(i * PB + rr) * OBs + j * PB + cc];
+      }
   __syncthreads();
+  const double4_t zero4 = {0.0, 0.0, 0.0, 0.0};
   for (int dist = 1; dist < nb; ++dist)
     for (int i = 0; i + dist < nb; ++i) {
       const int j = i + dist;
-      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+      double4_t acc = zero4;
       for (int l = i + 1; l <= j; ++l) {
+        const double* A = gb(i, l);
+        const double* Bm = xb(l, j);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int e = tid + 256 * q, r = e >> 5, cc = e & 31;
-          Gs[r * LS + cc] = G[size_t(i * PB + r) * OBs + l * PB + cc];
-          Xs[r * LS + cc] = X[size_t(l * PB + r) * OBs + j * PB + cc];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int e = tid + 256 * q, r = e >> 5, cc = e & 31;
-#pragma unroll 8
-          for (int m = 0; m < PB; ++m) acc[q] = fma(Gs[r * LS + m], Xs[m * LS + cc], acc[q]);
-        }
-        __syncthreads();
+        for (int k4 = 0; k4 < PB / 4; ++k4) acc = LG_MFMA(A[(tm * 16 + r) * LS + k4 * 4 + gq], Bm[(k4 * 4 + gq) * LS + tn * 16 + r], acc);
       }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int e = tid + 256 * q, r = e >> 5, cc = e & 31;
-        tmp[r * LS + cc] = acc[q];
-        Ts[r * LS + cc] = tp[i * PB * PB + e];
-      }
+      for (int q = 0; q < 4; ++q) tmp[(tm * 16 + 4 * q + gq) * LS + tn * 16 + r] = acc[q];
       __syncthreads();
+      const double* Ti = xb(i, i);
+      double4_t o = zero4;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int e = tid + 256 * q, r = e >> 5, cc = e & 31;
-        double o = 0.0;
-#pragma unroll 8
-        for (int m = 0; m < PB; ++m) o = fma(Ts[r * LS + m], tmp[m * LS + cc], o);
-        X[size_t(i * PB + r) * OBs + j * PB + cc] = -o;
-      }
+      for (int k4 = 0; k4 < PB / 4; ++k4) o = LG_MFMA(Ti[(tm * 16 + r) * LS + k4 * 4 + gq], tmp[(k4 * 4 + gq) * LS + tn * 16 + r], o);
+      double* Xo = xb(i, j);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Xo[(tm * 16 + 4 * q + gq) * LS + tn * 16 + r] = -o[q];
       __syncthreads();
     }
+  for (int e = tid; e < OBs * OBs; e += 256) {
+    const int rr = e / OBs, cc = e % OBs, bi = rr / PB, bj = cc / PB;
+    X[e] = (bi <= bj) ? xb(bi, bj)[(rr % PB) * LS + cc % PB] : 0.0;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1150,7 +1155,16 @@ static void blocked_lq(const DenseView& v, int rows_total, hipStream_t s) {
     const long sT = 128 * 128;
     Gemm gg{Vo, Vo, nullptr, v.lgGram, sDD, sDD, 0, sT, D, D, 0, OB, OB, OB, D, 1.0, 0.0, v.act, nullptr};
     gemm(v, s, B, true, gg);  // Gram = V V^T
-    hipLaunchKernelGGL(tf_outer_kernel, dim3(B), dim3(256), 0, s, v.lgTf, v.lgGram, v.lgTfo, nb, v.act);
+    {
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      static bool attr[64] = {};  // the opt-in to > 64 KB of dynamic LDS is per function AND per device
+      if (!attr[dev & 63]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tf_outer_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(kTfOuterShm));
+        attr[dev & 63] = true;
+      }
+    }
+    hipLaunchKernelGGL(tf_outer_kernel, dim3(B), dim3(256), kTfOuterShm, s, v.lgTf, v.lgGram, v.lgTfo, nb, v.act);
     Gemm g1{Mb, Vo, Tb, v.lgG, sDD, sDD, sDD, sG, D, D, D, OB, rows, OB, D, 1.0, 1.0, v.act, nullptr};
     gemm(v, s, B, true, g1);
     Gemm g2{v.lgG, v.lgTfo, nullptr, v.lgW, sG, sT, 0, sG, OB, OB, 0, OB, rows, OB, OB, 1.0, 0.0, v.act, nullptr};
