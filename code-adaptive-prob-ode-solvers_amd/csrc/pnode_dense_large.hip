@@ -664,22 +664,31 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ S
   if (act && !act[b]) return;
   double* A = S + size_t(b) * d * d;
   const int tid = threadIdx.x;
-  for (int e = tid; e < PB * PB; e += 256) {
-    const int i = e >> 5, j = e & 31;
-    Ld[i * (PB + 1) + j] = (j <= i) ? A[size_t(j0 + i) * d + j0 + j] : 0.0;
+  // The 32 x 32 diagonal block by ONE wavefront, lane i <-> row i in registers: the pivot and the column under it travel by v_readlane, no
+  // barrier inside the 32 pivots (r04; before: all four wavefronts on the block in LDS, three barriers per pivot -- 16 of the kernel's 27 us).
+  if (tid < 64) {
+    const int i = tid & 31;  // (lanes 32 .. 63 repeat lanes 0 .. 31: same values, same addresses)
+    double x[PB];
+    const double* ai = A + size_t(j0 + i) * d + j0;
+#pragma unroll
+    for (int j = 0; j < PB; ++j) x[j] = (j <= i) ? ai[j <= i ? j : 0] : 0.0;
+#pragma unroll
+    for (int c = 0; c < PB; ++c) {
+      // column c of the rows below: x[c] of lane c is the pivot
+      const double dc = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x[c]), c), __builtin_amdgcn_readlane(__double2loint(x[c]), c));
+      const double piv = sqrt(dc);
+      x[c] = (i == c) ? piv : ((i > c) ? x[c] / piv : x[c]);
+#pragma unroll
+      for (int j = c + 1; j < PB; ++j) {
+        // L[j][c], held by lane j
+        const double ljc = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x[c]), j), __builtin_amdgcn_readlane(__double2loint(x[c]), j));
+        x[j] = (i >= j) ? fma(-x[c], ljc, x[j]) : x[j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < PB; ++j) Ld[i * (PB + 1) + j] = (j <= i) ? x[j] : 0.0;
   }
   __syncthreads();
-  for (int c = 0; c < PB; ++c) {
-    const double piv = sqrt(Ld[c * (PB + 1) + c]);
-    __syncthreads();
-    if (tid >= c && tid < PB) Ld[tid * (PB + 1) + c] = (tid == c) ? piv : Ld[tid * (PB + 1) + c] / piv;
-    __syncthreads();
-    for (int e = tid; e < PB * PB; e += 256) {
-      const int i = e >> 5, j = e & 31;
-      if (i > c && j > c && j <= i) Ld[i * (PB + 1) + j] -= Ld[i * (PB + 1) + c] * Ld[j * (PB + 1) + c];
-    }
-    __syncthreads();
-  }
   for (int e = tid; e < PB * PB; e += 256) {
     const int i = e >> 5, j = e & 31;
     A[size_t(j0 + i) * d + j0 + j] = Ld[i * (PB + 1) + j];  // upper part of the block zeroed
